@@ -1,0 +1,87 @@
+"""ctypes binding of libmfnet_hip.so (C ABI declared in include/mfnet_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmfnet_hip.so")
+
+F32, BF16 = 0, 1
+
+
+class MfnetError(RuntimeError):
+    pass
+
+
+_lib = None
+
+P, I64, I, F = c_void_p, c_int64, c_int, c_float
+
+# name -> argtypes (all return int status); mirrors include/mfnet_hip.h
+_SIGS = {
+    "mfnet_layernorm_fwd": [P, I, I64, P, P, P, I, I64, P, P, I64, I64, F, P],
+    "mfnet_layernorm_bwd": [P, I, I64, P, I, I64, P, P, P, P, P, P, I64, P, P, I64, I64, P],
+    "mfnet_gemm_bf16": [P, I64, P, I64, I64, I64, I64, P, P, I64, P, I64, I64, I, I, F, I, P, I64, P, I64,
+                        P, I64, I64, P, I, I64, P],
+    "mfnet_skinny_nt": [P, I64, P, I64, P, I64, I64, I64, I, F, P],
+    "mfnet_skinny_tn": [P, I64, P, I64, P, I64, I64, I, I, F, P],
+    "mfnet_cast": [P, I, P, I, I64, P],
+    "mfnet_im2col_patch": [P, P, P, I64, I64, I64, I64, P],
+    "mfnet_im2col3x3": [P, P, I64, I64, I64, I64, P],
+    "mfnet_col2im3x3": [P, P, I64, I64, I64, I64, P],
+    "mfnet_lora_mix_fwd": [P, P, P, P, I64, I, P],
+    "mfnet_lora_mix_bwd": [P, P, P, P, P, P, I64, I, P],
+    "mfnet_attn_fwd": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, F, P],
+    "mfnet_attn_bwd": [P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, F, P],
+    "mfnet_ce_loss_fwd": [P, P, P, P, P, I64, I64, I64, I64, P],
+    "mfnet_ce_loss_bwd": [P, P, P, P, P, F, I64, I64, I64, I64, P],
+    "mfnet_sgd_flat": [P, P, P, I64, F, F, F, P],
+    "mfnet_tile_accumulate": [P, P, P, I64, I64, I64, I64, I64, I64, I, P],
+    "mfnet_argmax_chw": [P, P, I64, I64, P],
+    "mfnet_minmax": [P, P, I64, P],
+    "mfnet_scale_shift": [P, P, P, F, I64, I, P],
+    "mfnet_adapter_mix": [P, P, P, P, P, P, I64, I64, P],
+    "mfnet_adapter_mix_bwd": [P, P, P, P, P, P, P, I64, I64, P],
+    "mfnet_gelu_fwd": [P, P, I64, P],
+    "mfnet_gelu_bwd": [P, P, P, I64, P],
+    "mfnet_add_bf16": [P, P, P, I64, P],
+    "mfnet_bias_grad": [P, I64, P, I64, I64, P],
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MfnetError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C ssrs_amd/csrc`). There is no CPU / eager fallback for the MFNet hot path.")
+        L = ctypes.CDLL(LIB_PATH)
+        L.mfnet_last_error.restype = c_char_p
+        L.mfnet_last_error.argtypes = []
+        L.mfnet_version.restype = c_int
+        L.mfnet_version.argtypes = []
+        for name, sig in _SIGS.items():
+            fn = getattr(L, name, None)
+            if fn is None:
+                raise MfnetError(f"libmfnet_hip.so does not export {name}")
+            fn.restype = c_int
+            fn.argtypes = sig
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return ["mfnet_version", "mfnet_last_error"] + list(_SIGS)
+
+
+def call(name: str, *args):
+    L = lib()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        raise MfnetError(f"{name} failed ({rc}): {L.mfnet_last_error().decode()}")

@@ -1,0 +1,275 @@
+// bf16 MFMA GEMM with fused epilogues for the stacked-modality token matrix:
+//
+//   C[m,n] = sum_k A[m,k] * W[n,k]                       (A: [M,K] bf16, W: [N,K] bf16, fp32 accumulate)
+//          + bias[n]
+//          + lr_scale * sum_{j<R} U[m,j] * V[g(m)][n,j]   (fp32 low-rank update: LoRA fwd / LoRA dgrad)
+//          -> act: none | GELU (optionally also stores the pre-activation) | multiply by GELU'(aux[m,n])
+//          + residual[m % res_row_mod, n]                 (fp32; may alias the fp32 output)
+//          -> out (bf16 or fp32)
+//
+// It serves every dense contraction of the ViT blocks (lora_block.py:169-196 qkv/proj, :104-108 MLP,
+// loralib/layers.py:149-165,244-268 low-rank terms), their dgrads (W passed pre-transposed), the
+// patch-embed im2col GEMM (image_encoder.py:189-197) and the neck convs (:104-120).
+//
+// Design (gfx950): 128x128x64 tiles, 256 threads = 4 waves in 2x2, 64x64 per wave as 4x4
+// mfma_f32_16x16x32_bf16 tiles; A/W tiles land in LDS by global_load_lds (16 B/lane) into a
+// lane-linear image, XOR-swizzled on the SOURCE address so ds_read_b128 fragment reads are
+// conflict-free; double-buffered, one barrier per K-step. The weight rows are the MFMA "A" operand
+// and are read in a permuted order so every lane ends up owning 16 CONSECUTIVE output columns of one
+// row: the epilogue loads bias/V/residual and stores C with 16-byte accesses. Workgroup ids are
+// remapped so each XCD walks a contiguous run of tiles (shared A panel in its private L2).
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define GEMM_MAX_R 16
+
+struct GemmParams {
+  const bf16_t* A; int64_t lda;
+  const bf16_t* W; int64_t ldw;
+  int M, N, K;
+  const float* bias;
+  const float* U; int64_t ldu;
+  const float* V; int64_t v_group_stride; int64_t rows_per_group; int n_groups; int R; float lr_scale;
+  int act;                              // 0 none, 1 gelu, 2 multiply by gelu'(aux)
+  const bf16_t* aux; int64_t ldaux;
+  bf16_t* out_pre; int64_t ldpre;
+  const float* residual; int64_t ldres; int64_t res_row_mod;
+  void* out; int out_dtype; int64_t ldc;
+  int tiles_m, tiles_n;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __forceinline__ int swz_x(int row) { return row & 7; }
+__device__ __forceinline__ int swz_w(int row) { return (((row >> 4) & 3) << 1) | ((row >> 1) & 1); }
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (BM + BN) * BK * 2];  // 64 KiB
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware bijective remap of the workgroup id (8 XCDs, round-robin dispatch)
+  const int nwg = p.tiles_m * p.tiles_n;
+  int wg;
+  {
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- staging addresses: this wave fills rows [wave*32, wave*32+32) of both tiles, 8 rows/instr
+  const int srow = lane >> 3;        // 0..7 within an 8-row group
+  const int sch = lane & 7;          // destination chunk (16 B) inside the 128-B row
+  const bf16_t* a_src[4];
+  const bf16_t* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + srow;
+    int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
+    int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
+    a_src[i] = p.A + (int64_t)gm * p.lda + ((sch ^ swz_x(row)) << 3);
+    w_src[i] = p.W + (int64_t)gn * p.ldw + ((sch ^ swz_w(row)) << 3);
+  }
+  auto stage = [&](int kt, int buf) {
+    unsigned char* base = lds + buf * ((BM + BN) * BK * 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + kt * BK),
+                                       (lds_ptr_t)(base + (wave * 4 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[i] + kt * BK),
+                                       (lds_ptr_t)(base + BM * BK * 2 + (wave * 4 + i) * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment read offsets (bytes, without the per-k-step chunk XOR)
+  const int fr = lane & 15, fq = lane >> 4;
+  int x_off[4], x_sw[4], w_off[4], w_sw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int xr = wm * 64 + i * 16 + fr;
+    x_off[i] = xr * 128; x_sw[i] = swz_x(xr);
+    const int wr = wn * 64 + 16 * (fr >> 2) + 4 * i + (fr & 3);
+    w_off[i] = BM * BK * 2 + wr * 128; w_sw[i] = swz_w(wr);
+  }
+
+  f32x4_t acc[4][4];   // [ni][mi]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nt = p.K / BK;
+  stage(0, 0);
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+    const unsigned char* base = lds + (t & 1) * ((BM + BN) * BK * 2);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t xf[4], wf[4];
+      const int ch = fq + 4 * ks;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xf[i] = *reinterpret_cast<const bf16x8_t*>(base + x_off[i] + ((ch ^ x_sw[i]) << 4));
+        wf[i] = *reinterpret_cast<const bf16x8_t*>(base + w_off[i] + ((ch ^ w_sw[i]) << 4));
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane owns rows m(mi) = m0+wm*64+mi*16+fr and columns nb..nb+15
+  const int nb = n0 + wn * 64 + 16 * fq;
+  if (nb >= p.N) return;
+  int mrow[4];
+  bool mok[4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    mrow[mi] = m0 + wm * 64 + mi * 16 + fr;
+    mok[mi] = mrow[mi] < p.M;
+  }
+  if (p.bias) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const float4 b = *reinterpret_cast<const float4*>(p.bias + nb + 4 * ni);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        acc[ni][mi][0] += b.x; acc[ni][mi][1] += b.y; acc[ni][mi][2] += b.z; acc[ni][mi][3] += b.w;
+      }
+    }
+  }
+  if (p.U) {
+    const int R = p.R;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      if (!mok[mi]) continue;
+      float u[GEMM_MAX_R];
+      const float* up = p.U + (int64_t)mrow[mi] * p.ldu;
+#pragma unroll
+      for (int j = 0; j < GEMM_MAX_R; j += 4) {
+        if (j < R) {
+          const float4 t4 = *reinterpret_cast<const float4*>(up + j);
+          u[j] = t4.x * p.lr_scale; u[j + 1] = t4.y * p.lr_scale; u[j + 2] = t4.z * p.lr_scale; u[j + 3] = t4.w * p.lr_scale;
+        } else { u[j] = u[j + 1] = u[j + 2] = u[j + 3] = 0.f; }
+      }
+      const int g = p.n_groups > 1 ? (int)((mrow[mi] / p.rows_per_group) % p.n_groups) : 0;
+      const float* vp = p.V + (int64_t)g * p.v_group_stride + (int64_t)nb * R;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* vr = vp + (int64_t)(4 * ni + r) * R;
+          float s = 0.f;
+#pragma unroll
+          for (int j = 0; j < GEMM_MAX_R; j += 4) {
+            if (j < R) {
+              const float4 v4 = *reinterpret_cast<const float4*>(vr + j);
+              s += u[j] * v4.x + u[j + 1] * v4.y + u[j + 2] * v4.z + u[j + 3] * v4.w;
+            }
+          }
+          acc[ni][mi][r] += s;
+        }
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    if (!mok[mi]) continue;
+    const int64_t m = mrow[mi];
+    float v[16];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[4 * ni + r] = acc[ni][mi][r];
+    if (p.act == 1) {
+      if (p.out_pre) {
+        u32x4_t w0, w1;
+        w0.x = pack_bf16x2(v[0], v[1]); w0.y = pack_bf16x2(v[2], v[3]); w0.z = pack_bf16x2(v[4], v[5]); w0.w = pack_bf16x2(v[6], v[7]);
+        w1.x = pack_bf16x2(v[8], v[9]); w1.y = pack_bf16x2(v[10], v[11]); w1.z = pack_bf16x2(v[12], v[13]); w1.w = pack_bf16x2(v[14], v[15]);
+        u32x4_t* dst = reinterpret_cast<u32x4_t*>(p.out_pre + m * p.ldpre + nb);
+        dst[0] = w0; dst[1] = w1;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = gelu_f(v[i]);
+    } else if (p.act == 2) {
+      const u32x4_t* ap = reinterpret_cast<const u32x4_t*>(p.aux + m * p.ldaux + nb);
+      const u32x4_t a0 = ap[0], a1 = ap[1];
+      const unsigned int aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[2 * i] *= gelu_grad_f(bf16_lo(aw[i]));
+        v[2 * i + 1] *= gelu_grad_f(bf16_hi(aw[i]));
+      }
+    }
+    if (p.residual) {
+      const int64_t rr = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
+      const float4* rp = reinterpret_cast<const float4*>(p.residual + rr * p.ldres + nb);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 r4 = rp[i];
+        v[4 * i] += r4.x; v[4 * i + 1] += r4.y; v[4 * i + 2] += r4.z; v[4 * i + 3] += r4.w;
+      }
+    }
+    if (p.out_dtype == MFNET_BF16) {
+      u32x4_t w0, w1;
+      w0.x = pack_bf16x2(v[0], v[1]); w0.y = pack_bf16x2(v[2], v[3]); w0.z = pack_bf16x2(v[4], v[5]); w0.w = pack_bf16x2(v[6], v[7]);
+      w1.x = pack_bf16x2(v[8], v[9]); w1.y = pack_bf16x2(v[10], v[11]); w1.z = pack_bf16x2(v[12], v[13]); w1.w = pack_bf16x2(v[14], v[15]);
+      u32x4_t* dst = reinterpret_cast<u32x4_t*>((bf16_t*)p.out + m * p.ldc + nb);
+      dst[0] = w0; dst[1] = w1;
+    } else {
+      float4* dst = reinterpret_cast<float4*>((float*)p.out + m * p.ldc + nb);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dst[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    }
+  }
+}
+
+extern "C" int mfnet_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int64_t N,
+                               int64_t K, const float* bias, const float* U, int64_t ldu, const float* V,
+                               int64_t v_group_stride, int64_t rows_per_group, int n_groups, int R,
+                               float lr_scale, int act, const void* aux, int64_t ldaux, void* out_pre,
+                               int64_t ldpre, const float* residual, int64_t ldres, int64_t res_row_mod,
+                               void* out, int out_dtype, int64_t ldc, hipStream_t stream) {
+  MF_CHECK_ARG(A && W && out, "gemm_bf16: null operand");
+  MF_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm_bf16: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
+  MF_CHECK_ARG(K % BK == 0, "gemm_bf16: K=%lld must be a multiple of %d", (long long)K, BK);
+  MF_CHECK_ARG(N % 16 == 0, "gemm_bf16: N=%lld must be a multiple of 16", (long long)N);
+  MF_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K, "gemm_bf16: lda/ldw must be >= K and multiples of 8");
+  MF_CHECK_ARG(ldc >= N && ldc % 8 == 0, "gemm_bf16: bad ldc");
+  MF_CHECK_ARG(((uintptr_t)A | (uintptr_t)W | (uintptr_t)out) % 16 == 0, "gemm_bf16: operands must be 16-byte aligned");
+  MF_CHECK_ARG(out_dtype == MFNET_BF16 || out_dtype == MFNET_F32, "gemm_bf16: bad out dtype");
+  MF_CHECK_ARG(act >= 0 && act <= 2, "gemm_bf16: bad act");
+  MF_CHECK_ARG(act != 2 || (aux && ldaux >= N && ldaux % 8 == 0), "gemm_bf16: act=2 needs aux");
+  MF_CHECK_ARG(!out_pre || (act == 1 && ldpre >= N && ldpre % 8 == 0), "gemm_bf16: out_pre needs act=1");
+  MF_CHECK_ARG(!residual || (ldres >= N && ldres % 4 == 0), "gemm_bf16: bad residual ld");
+  if (U) {
+    MF_CHECK_ARG(V && R > 0 && R <= GEMM_MAX_R && R % 4 == 0 && ldu >= R && ldu % 4 == 0, "gemm_bf16: bad low-rank args (R=%d)", R);
+    MF_CHECK_ARG(n_groups >= 1 && (n_groups == 1 || rows_per_group > 0), "gemm_bf16: bad group args");
+  }
+  MF_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31), "gemm_bf16: shape too large");
+  if (M == 0) return MFNET_OK;
+  GemmParams p;
+  p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.bias = bias;
+  p.U = U; p.ldu = ldu; p.V = V; p.v_group_stride = v_group_stride; p.rows_per_group = rows_per_group;
+  p.n_groups = n_groups; p.R = R; p.lr_scale = lr_scale; p.act = act;
+  p.aux = (const bf16_t*)aux; p.ldaux = ldaux; p.out_pre = (bf16_t*)out_pre; p.ldpre = ldpre;
+  p.residual = residual; p.ldres = ldres; p.res_row_mod = res_row_mod;
+  p.out = out; p.out_dtype = out_dtype; p.ldc = ldc;
+  p.tiles_m = (int)ceil_div64(M, BM); p.tiles_n = (int)ceil_div64(N, BN);
+  const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+  MF_CHECK_ARG(nwg < (1ll << 31), "gemm_bf16: too many tiles");
+  hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)nwg), dim3(256), 0, stream, p);
+  MF_LAUNCH_CHECK("gemm_bf16");
+  return MFNET_OK;
+}

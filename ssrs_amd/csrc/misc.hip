@@ -1,0 +1,196 @@
+// Small HBM-bound data-movement kernels of the encoder path: dtype casts, patch-embed im2col,
+// 3x3 im2col / col2im for the neck conv, the LoRA cross-modal mix (loralib/layers.py:159-160).
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------- cast
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const float4 a = reinterpret_cast<const float4*>(x)[2 * i];
+    const float4 b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+    u32x4_t w;
+    w.x = pack_bf16x2(a.x, a.y); w.y = pack_bf16x2(a.z, a.w); w.z = pack_bf16x2(b.x, b.y); w.w = pack_bf16x2(b.z, b.w);
+    reinterpret_cast<u32x4_t*>(y)[i] = w;
+  }
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const u32x4_t w = reinterpret_cast<const u32x4_t*>(x)[i];
+    reinterpret_cast<float4*>(y)[2 * i] = make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
+    reinterpret_cast<float4*>(y)[2 * i + 1] = make_float4(bf16_lo(w.z), bf16_hi(w.z), bf16_lo(w.w), bf16_hi(w.w));
+  }
+}
+static inline unsigned grid_for(int64_t work_items) {
+  int64_t g = ceil_div64(work_items, 256);
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+extern "C" int mfnet_cast(const void* x, int x_dtype, void* y, int y_dtype, int64_t n, hipStream_t stream) {
+  MF_CHECK_ARG(x && y, "cast: null pointer");
+  MF_CHECK_ARG(n >= 0 && n % 8 == 0, "cast: n=%lld must be a multiple of 8", (long long)n);
+  if (n == 0) return MFNET_OK;
+  if (x_dtype == MFNET_F32 && y_dtype == MFNET_BF16)
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, (const float*)x, (bf16_t*)y, n / 8);
+  else if (x_dtype == MFNET_BF16 && y_dtype == MFNET_F32)
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, (const bf16_t*)x, (float*)y, n / 8);
+  else { mfnet_set_error("cast: unsupported dtype pair"); return MFNET_ERR_ARG; }
+  MF_LAUNCH_CHECK("cast");
+  return MFNET_OK;
+}
+
+// ------------------------------------------------------------------------- patch-embed im2col
+// rgb [B,3,H,W] fp32 and dsm [B,H,W] fp32 (replicated to 3 channels, unetformer_mmsam.py:535) ->
+// cols [2*B*T, 3*P*P] bf16, row = (modality, b, ph, pw), k = c*P*P + py*P + px  (conv weight order,
+// image_encoder.py:189-197). One thread = 8 consecutive px.
+__global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restrict__ rgb, const float* __restrict__ dsm,
+                                                           bf16_t* __restrict__ cols, int B, int H, int W, int P) {
+  const int Sh = H / P, Sw = W / P;
+  const int K = 3 * P * P, K8 = K >> 3, P8 = P >> 3;
+  const int64_t total = (int64_t)2 * B * Sh * Sw * K8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int k8 = (int)(i % K8);
+    const int64_t row = i / K8;
+    const int px8 = k8 % P8, py = (k8 / P8) % P, c = k8 / (P8 * P);
+    const int pw = (int)(row % Sw), ph = (int)((row / Sw) % Sh);
+    const int b = (int)((row / ((int64_t)Sw * Sh)) % B), mod = (int)(row / ((int64_t)Sw * Sh * B));
+    const int y = ph * P + py, x = pw * P + px8 * 8;
+    const float* src = mod == 0 ? rgb + (((int64_t)b * 3 + c) * H + y) * W + x : dsm + ((int64_t)b * H + y) * W + x;
+    const float4 a = *reinterpret_cast<const float4*>(src), bb = *reinterpret_cast<const float4*>(src + 4);
+    u32x4_t w;
+    w.x = pack_bf16x2(a.x, a.y); w.y = pack_bf16x2(a.z, a.w); w.z = pack_bf16x2(bb.x, bb.y); w.w = pack_bf16x2(bb.z, bb.w);
+    *reinterpret_cast<u32x4_t*>(cols + row * K + (int64_t)k8 * 8) = w;
+  }
+}
+extern "C" int mfnet_im2col_patch(const float* rgb, const float* dsm, void* cols, int64_t B, int64_t H, int64_t W,
+                                  int64_t P, hipStream_t stream) {
+  MF_CHECK_ARG(rgb && dsm && cols, "im2col_patch: null pointer");
+  MF_CHECK_ARG(P > 0 && P % 8 == 0 && H % P == 0 && W % P == 0 && W % 4 == 0, "im2col_patch: bad geometry H=%lld W=%lld P=%lld", (long long)H, (long long)W, (long long)P);
+  if (B <= 0) return MFNET_OK;
+  const int64_t total = 2 * B * (H / P) * (W / P) * (3 * P * P / 8);
+  hipLaunchKernelGGL(im2col_patch_kernel, dim3(grid_for(total)), dim3(256), 0, stream, rgb, dsm, (bf16_t*)cols, (int)B, (int)H, (int)W, (int)P);
+  MF_LAUNCH_CHECK("im2col_patch");
+  return MFNET_OK;
+}
+
+// ------------------------------------------------------------------------- 3x3 im2col / col2im (NHWC)
+// x [G,H,W,C] bf16 -> cols [G*H*W, 9*C] bf16, k = tap*C + c, tap = ky*3+kx, zero padding 1.
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ cols,
+                                                        int G, int H, int W, int C) {
+  const int C8 = C >> 3;
+  const int64_t total = (int64_t)G * H * W * 9 * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int tap = (int)((i / C8) % 9);
+    const int64_t pix = i / (9 * C8);
+    const int xx = (int)(pix % W), yy = (int)((pix / W) % H);
+    const int64_t g = pix / ((int64_t)W * H);
+    const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
+    u32x4_t v = (u32x4_t){0u, 0u, 0u, 0u};
+    if (sy >= 0 && sy < H && sx >= 0 && sx < W)
+      v = *reinterpret_cast<const u32x4_t*>(x + ((g * H + sy) * W + sx) * C + c8 * 8);
+    *reinterpret_cast<u32x4_t*>(cols + pix * 9 * C + (int64_t)tap * C + c8 * 8) = v;
+  }
+}
+// dcols [G*H*W, 9*C] bf16 -> dx [G,H,W,C] fp32 : dx[p] = sum_tap dcols[p - off(tap)][tap]
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const bf16_t* __restrict__ dcols, float* __restrict__ dx,
+                                                        int G, int H, int W, int C) {
+  const int C8 = C >> 3;
+  const int64_t total = (int64_t)G * H * W * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t pix = i / C8;
+    const int xx = (int)(pix % W), yy = (int)((pix / W) % H);
+    const int64_t g = pix / ((int64_t)W * H);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      // output pixel q read input pixel p through `tap` iff p = q + (tap/3-1, tap%3-1)
+      const int qy = yy - (tap / 3 - 1), qx = xx - (tap % 3 - 1);
+      if (qy >= 0 && qy < H && qx >= 0 && qx < W) {
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(dcols + ((g * H + qy) * W + qx) * 9 * C + (int64_t)tap * C + c8 * 8);
+        acc[0] += bf16_lo(v.x); acc[1] += bf16_hi(v.x); acc[2] += bf16_lo(v.y); acc[3] += bf16_hi(v.y);
+        acc[4] += bf16_lo(v.z); acc[5] += bf16_hi(v.z); acc[6] += bf16_lo(v.w); acc[7] += bf16_hi(v.w);
+      }
+    }
+    float4* d = reinterpret_cast<float4*>(dx + pix * C + c8 * 8);
+    d[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    d[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+}
+extern "C" int mfnet_im2col3x3(const void* x, void* cols, int64_t G, int64_t H, int64_t W, int64_t C, hipStream_t stream) {
+  MF_CHECK_ARG(x && cols && C > 0 && C % 8 == 0, "im2col3x3: bad args");
+  if (G * H * W <= 0) return MFNET_OK;
+  hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid_for(G * H * W * 9 * (C / 8))), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)cols, (int)G, (int)H, (int)W, (int)C);
+  MF_LAUNCH_CHECK("im2col3x3");
+  return MFNET_OK;
+}
+extern "C" int mfnet_col2im3x3(const void* dcols, float* dx, int64_t G, int64_t H, int64_t W, int64_t C, hipStream_t stream) {
+  MF_CHECK_ARG(dcols && dx && C > 0 && C % 8 == 0, "col2im3x3: bad args");
+  if (G * H * W <= 0) return MFNET_OK;
+  hipLaunchKernelGGL(col2im3x3_kernel, dim3(grid_for(G * H * W * (C / 8))), dim3(256), 0, stream, (const bf16_t*)dcols, dx, (int)G, (int)H, (int)W, (int)C);
+  MF_LAUNCH_CHECK("col2im3x3");
+  return MFNET_OK;
+}
+
+// ------------------------------------------------------------------------- LoRA cross-modal mix
+// a [M, r] fp32 holds ax = x@Ax^T for the first M/2 rows and ay = y@Ay^T for the rest.
+// U [M, 2r]: x rows -> [wx*ax, (1-wx)*ay] ; y rows -> [(1-wy)*ax, wy*ay]   (loralib/layers.py:159-160)
+__global__ __launch_bounds__(256) void lora_mix_fwd_kernel(const float* __restrict__ a, const float* __restrict__ wx,
+                                                           const float* __restrict__ wy, float* __restrict__ U,
+                                                           int64_t Mh, int r) {
+  const float fx = wx[0], fy = wy[0];
+  const int64_t total = Mh * r;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / r;
+    const int j = (int)(i % r);
+    const float ax = a[t * r + j], ay = a[(Mh + t) * r + j];
+    U[t * 2 * r + j] = fx * ax;
+    U[t * 2 * r + r + j] = (1.f - fx) * ay;
+    U[(Mh + t) * 2 * r + j] = (1.f - fy) * ax;
+    U[(Mh + t) * 2 * r + r + j] = fy * ay;
+  }
+}
+// P [M, 2r] = g @ [Bx|By].  da [M, r]: x rows <- wx*Px[:, :r] + (1-wy)*Py[:, :r] ; y rows <- (1-wx)*Px[:, r:] + wy*Py[:, r:]
+// dw[0] += sum Px[:, :r]*ax - Px[:, r:]*ay ; dw[1] += sum Py[:, r:]*ay - Py[:, :r]*ax
+__global__ __launch_bounds__(256) void lora_mix_bwd_kernel(const float* __restrict__ P, const float* __restrict__ a,
+                                                           const float* __restrict__ wx, const float* __restrict__ wy,
+                                                           float* __restrict__ da, float* __restrict__ dw, int64_t Mh, int r) {
+  const float fx = wx[0], fy = wy[0];
+  const int64_t total = Mh * r;
+  float sx = 0.f, sy = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / r;
+    const int j = (int)(i % r);
+    const float ax = a[t * r + j], ay = a[(Mh + t) * r + j];
+    const float pxx = P[t * 2 * r + j], pxy = P[t * 2 * r + r + j];
+    const float pyx = P[(Mh + t) * 2 * r + j], pyy = P[(Mh + t) * 2 * r + r + j];
+    da[t * r + j] = fx * pxx + (1.f - fy) * pyx;
+    da[(Mh + t) * r + j] = (1.f - fx) * pxy + fy * pyy;
+    sx += pxx * ax - pxy * ay;
+    sy += pyy * ay - pyx * ax;
+  }
+  sx = wave_sum(sx);
+  sy = wave_sum(sy);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(dw, sx);
+    atomicAdd(dw + 1, sy);
+  }
+}
+extern "C" int mfnet_lora_mix_fwd(const float* a, const float* wx, const float* wy, float* U, int64_t M, int r, hipStream_t stream) {
+  MF_CHECK_ARG(a && wx && wy && U && r > 0 && M % 2 == 0, "lora_mix_fwd: bad args");
+  if (M == 0) return MFNET_OK;
+  hipLaunchKernelGGL(lora_mix_fwd_kernel, dim3(grid_for(M / 2 * r)), dim3(256), 0, stream, a, wx, wy, U, M / 2, r);
+  MF_LAUNCH_CHECK("lora_mix_fwd");
+  return MFNET_OK;
+}
+// dw (2 floats: d lora_wx, d lora_wy) is accumulated into; zero it first.
+extern "C" int mfnet_lora_mix_bwd(const float* P, const float* a, const float* wx, const float* wy, float* da, float* dw,
+                                  int64_t M, int r, hipStream_t stream) {
+  MF_CHECK_ARG(P && a && wx && wy && da && dw && r > 0 && M % 2 == 0, "lora_mix_bwd: bad args");
+  if (M == 0) return MFNET_OK;
+  unsigned g = grid_for(M / 2 * r);
+  if (g > 256) g = 256;
+  hipLaunchKernelGGL(lora_mix_bwd_kernel, dim3(g), dim3(256), 0, stream, P, a, wx, wy, da, dw, M / 2, r);
+  MF_LAUNCH_CHECK("lora_mix_bwd");
+  return MFNET_OK;
+}

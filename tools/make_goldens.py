@@ -1,0 +1,300 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE (imported from /root/reference, CPU).
+
+Runs only in the build container (the reference never travels). Inputs/weights come from the
+closed form in ssrs_amd/detfill.py, so the fixtures hold only expected outputs (+ tiny metadata).
+Import-time stubs replace packages the image lacks (timm, cv2, torchvision, skimage, IPython,
+rasterio, geopandas, shapely); none of them is on the hot path's arithmetic.
+
+    python tools/make_goldens.py [case ...]      # default: all cases
+"""
+import argparse
+import functools
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from ssrs_amd import detfill  # noqa: E402
+
+REF = "/root/reference"
+GOLD = os.path.join(REPO, "tests", "golden")
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+class _DropPath(nn.Module):          # only reached if drop_path > 0 (never in MFNet)
+    def __init__(self, p=0.0):
+        super().__init__()
+
+    def forward(self, x):
+        return x
+
+
+def install_stubs():
+    _stub("timm"); _stub("timm.models")
+    _stub("timm.models.layers", DropPath=_DropPath, to_2tuple=lambda x: (x, x),
+          trunc_normal_=nn.init.trunc_normal_)
+    _stub("cv2"); _stub("torchvision"); _stub("torchvision.transforms")
+    _stub("torchvision.transforms.functional", resize=None, to_pil_image=None)
+    _stub("torchvision.ops"); _stub("torchvision.ops.boxes", batched_nms=None, box_area=None)
+    _stub("torchvision.utils", make_grid=None)
+    _stub("skimage", io=types.SimpleNamespace(imread=None, imsave=None))
+    _stub("skimage.io", imread=None, imsave=None)
+    _stub("IPython"); _stub("IPython.display", clear_output=lambda **k: None)
+    _stub("rasterio", Affine=object); _stub("rasterio.transform", from_bounds=None)
+    _stub("rasterio.warp", reproject=None, Resampling=None); _stub("rasterio.features", shapes=None)
+    _stub("geopandas", GeoDataFrame=object); _stub("shapely"); _stub("shapely.geometry", shape=None, Polygon=object, MultiPolygon=object)
+    _stub("shapely.ops", unary_union=None)
+
+
+def enter_scratch():
+    d = os.path.join(REPO, ".scratch", "goldens_cwd")
+    os.makedirs(os.path.join(d, "weights"), exist_ok=True)
+    os.chdir(d)
+    # a LOCAL empty checkpoint keeps build_sam off its (offline-unreachable) download branch
+    torch.save({}, "weights/sam_vit_l_0b3195.pth")
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def summarize(t: torch.Tensor, n=256):
+    """(l2 norm, sum, first n elements) - compact pin for big tensors."""
+    f = t.detach().double().flatten()
+    return np.concatenate([[f.norm().item(), f.sum().item()], f[:n].numpy()])
+
+
+# --------------------------------------------------------------------------------------------
+def case_blocks():
+    """Tiny LoraBlock / AdapterFusionBlock, windowed + global, S in {16, 20} (padded windows and
+    rel-pos interpolation paths), fwd + all grads."""
+    from medsam.models.ImageEncoder.vit.lora_block import LoraBlock
+    from medsam.models.ImageEncoder.vit.adapter_fusionblock import AdapterFusionBlock
+    dim, heads = 128, 2
+    norm = functools.partial(nn.LayerNorm, eps=1e-6)
+    for kind, cls in (("lora", LoraBlock), ("adpt", AdapterFusionBlock)):
+        for ws in (14, 0):
+            for S in (16, 20):
+                tag = f"block_{kind}_w{ws}_s{S}"
+                args = argparse.Namespace(mod="sam_lora" if kind == "lora" else "sam_adpt",
+                                          mid_dim=None, image_size=1024)
+                blk = cls(args=args, dim=dim, num_heads=heads, mlp_ratio=4.0, qkv_bias=True,
+                          norm_layer=norm, act_layer=nn.GELU, use_rel_pos=True, rel_pos_zero_init=True,
+                          window_size=ws, input_size=(64, 64))
+                blk.load_state_dict(detfill.fill_state_dict(blk.state_dict(), tag + "/"))
+                B = 1
+                x = torch.from_numpy(detfill.uniform(tag + "/x", (B, S, S, dim))).float().requires_grad_()
+                y = torch.from_numpy(detfill.uniform(tag + "/y", (B, S, S, dim))).float().requires_grad_()
+                gx = torch.from_numpy(detfill.uniform(tag + "/gx", (B, S, S, dim))).float()
+                gy = torch.from_numpy(detfill.uniform(tag + "/gy", (B, S, S, dim))).float()
+                ox, oy = blk(x, y)
+                ((ox * gx).sum() + (oy * gy).sum()).backward()
+                arrs = dict(out_x=ox, out_y=oy, grad_x=x.grad, grad_y=y.grad)
+                for n, p_ in blk.named_parameters():
+                    if p_.grad is not None:
+                        arrs["g/" + n] = p_.grad
+                save(tag, **arrs)
+
+
+def _tiny_builder(depth=2, dim=128, heads=2, glob=(1,)):
+    import medsam.models.sam  # noqa: F401  (the package re-exports a *function* named build_sam)
+    BS = sys.modules["medsam.models.sam.build_sam"]
+    return lambda args, checkpoint=None: BS._build_sam(
+        args, encoder_embed_dim=dim, encoder_depth=depth, encoder_num_heads=heads,
+        encoder_global_attn_indexes=list(glob), checkpoint=checkpoint)
+
+
+def _build_model(mod, builder_name, num_classes=6):
+    """UNetFormer from the unmodified reference; the ctor hard-codes registry key 'vit_l'
+    (unetformer_mmsam.py:489), so that dict entry is rebound (no source edit)."""
+    sys.argv = ["oracle", "-mod", mod]
+    import unetformer_mmsam as U
+    BS = sys.modules["medsam.models.sam.build_sam"]
+    U.sam_model_registry["vit_l"] = _tiny_builder() if builder_name == "tiny" else BS.sam_model_registry[builder_name]
+    m = U.UNetFormer(num_classes=num_classes)
+    if mod == "sam_adpt":       # README.md:12-13: the freeze filter is hand-edited to 'Adapter'
+        for n, p_ in m.image_encoder.named_parameters():
+            p_.requires_grad = "Adapter" in n
+    return m
+
+
+def case_encoder():
+    """Tiny ImageEncoderViT (depth 2: one windowed + one global block), both mods, B=1, 256^2."""
+    for mod in ("sam_lora", "sam_adpt"):
+        tag = f"encoder_tiny_{mod}"
+        m = _build_model(mod, "tiny")
+        enc = m.image_encoder
+        enc.load_state_dict(detfill.fill_state_dict(enc.state_dict(), tag + "/"))
+        enc.eval()
+        x = torch.from_numpy(detfill.uniform(tag + "/x", (1, 3, 256, 256))).float()
+        y = torch.from_numpy(detfill.uniform(tag + "/y", (1, 3, 256, 256))).float()
+        with torch.no_grad():
+            fx, fy = enc(x, y)
+        save(tag, fx=fx, fy=fy)
+
+
+def _train_step_arrays(m, tag, B, ncls, ignore=None, size=256):
+    import torch.nn.functional as F
+    rgb, dsm, tgt = detfill.tiles(tag, B, size, ncls)
+    if ignore is not None:
+        tgt = tgt.clone(); tgt[:, :32, :48] = ignore
+    m.train()
+    m.decoder.segmentation_head[1].p = 0.0        # Dropout2d off: RNG-free parity (SURVEY 'hard parts')
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
+    arrs = {}
+    for step in range(2):
+        opt.zero_grad()
+        out = m(rgb, dsm)
+        flat = out.view(out.size(0), out.size(1), -1).transpose(1, 2).contiguous().view(-1, out.size(1))
+        if ignore is None:
+            loss = F.cross_entropy(flat, tgt.view(-1), torch.ones(ncls))
+        else:
+            loss = F.cross_entropy(flat, tgt.view(-1), ignore_index=ignore)
+        loss.backward()
+        arrs[f"loss{step}"] = loss.detach()
+        if step == 0:
+            arrs["logits_s4"] = out[:, :, ::4, ::4]
+            names = []
+            for n, p_ in m.named_parameters():
+                if p_.grad is not None:
+                    names.append(n)
+                    arrs["g/" + n] = summarize(p_.grad)
+            arrs["grad_names"] = np.array(names)
+        opt.step()
+    for n, p_ in m.named_parameters():
+        if p_.grad is not None:
+            arrs["p/" + n] = summarize(p_)
+    for n, b in m.named_buffers():
+        if "running_" in n or "num_batches" in n:
+            arrs["b/" + n] = b.double() if b.numel() < 300 else summarize(b)
+    return arrs
+
+
+def case_model_tiny():
+    """Full UNetFormer on a tiny ViT (depth 2, dim 128): eval logits, then two train steps
+    (CE + SGD momentum) with Dropout2d disabled; both mods; plus the ignore_index=255 loss."""
+    for mod in ("sam_lora", "sam_adpt"):
+        tag = f"model_tiny_{mod}"
+        m = _build_model(mod, "tiny")
+        m.load_state_dict(detfill.fill_state_dict(m.state_dict(), tag + "/"))
+        rgb, dsm, _ = detfill.tiles(tag, 2, 256, 6)
+        m.eval()
+        with torch.no_grad():
+            out = m(rgb, dsm)
+        arrs = dict(eval_logits_s4=out[:, :, ::4, ::4], eval_argmax=out.argmax(1).to(torch.uint8),
+                    eval_chan_sum=out.double().sum((0, 2, 3)))
+        arrs.update(_train_step_arrays(m, tag, 2, 6))
+        save(tag, **arrs)
+    tag = "model_tiny_ignore255"
+    m = _build_model("sam_lora", "tiny", num_classes=2)
+    m.load_state_dict(detfill.fill_state_dict(m.state_dict(), tag + "/"))
+    save(tag, **_train_step_arrays(m, tag, 2, 2, ignore=255))
+
+
+def case_model_vitb():
+    """ViT-B MMLoRA (BASELINE config 1): eval logits B=1 + per-block residual checksums; one
+    fwd+bwd+SGD train step at B=2. ViT-B MMAdapter: eval logits B=1."""
+    for mod in ("sam_lora", "sam_adpt"):
+        tag = f"model_vitb_{mod}"
+        m = _build_model(mod, "vit_b")
+        m.load_state_dict(detfill.fill_state_dict(m.state_dict(), tag + "/"))
+        rgb, dsm, _ = detfill.tiles(tag, 1, 256, 6)
+        m.eval()
+        sums = []
+        hooks = [b.register_forward_hook(lambda mod_, i, o: sums.append(
+            [o[0].double().abs().mean().item(), o[1].double().abs().mean().item(),
+             o[0].double().sum().item(), o[1].double().sum().item()])) for b in m.image_encoder.blocks]
+        with torch.no_grad():
+            out = m(rgb, dsm)
+        for h in hooks:
+            h.remove()
+        arrs = dict(eval_logits_s4=out[:, :, ::4, ::4], eval_argmax=out.argmax(1).to(torch.uint8),
+                    eval_chan_sum=out.double().sum((0, 2, 3)), block_sums=np.array(sums))
+        if mod == "sam_lora":
+            arrs.update(_train_step_arrays(m, tag, 2, 6))
+        save(tag, **arrs)
+
+
+def case_sliding():
+    """utils2.sliding_window / count_sliding_window / grouper and inference._get_sliding_windows
+    index lists; evaluator._predict_image with a cheap stand-in model (clamped-tail duplicates)."""
+    import utils2
+    arrs = {}
+    for (H, W, step, win) in ((600, 700, 64, 256), (512, 512, 32, 256), (256, 256, 64, 256),
+                              (300, 1000, 192, 256), (1024, 777, 100, 256)):
+        top = np.zeros((H, W, 3), np.float32)
+        c = np.array(list(utils2.sliding_window(top, step=step, window_size=(win, win))))
+        assert len(c) == utils2.count_sliding_window(top, step=step, window_size=(win, win))
+        arrs[f"sw_{H}_{W}_{step}_{win}"] = c
+    arrs["grouper_10_3"] = np.array([len(g) for g in utils2.grouper(3, range(10))])
+    import inference
+    for (H, W, ov) in ((600, 700, 64), (256, 256, 64), (8192, 8192, 64), (1000, 333, 0), (383, 384, 128), (1030, 520, 64)):
+        ns = types.SimpleNamespace(window_size=(256, 256), overlap=ov)
+        arrs[f"inf_{H}_{W}_{ov}"] = np.array(inference.BuildingInference._get_sliding_windows(ns, H, W))
+
+    # evaluator._predict_image with a stand-in model; Tensor.cuda is made the identity (no GPU
+    # here) - an environment stub, no arithmetic changes.
+    import evaluator as EV
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    H, W, ncls = 600, 700, 2
+    img = (0.5 * (detfill.uniform("sliding/img", (H, W, 3)) + 1)).astype(np.float32)
+    dsm = (37.0 + 11.0 * detfill.uniform("sliding/dsm", (H, W))).astype(np.float32)
+
+    class Standin:
+        def forward(self, ip, dp, mode="Test"):
+            a = ip.mean(1) * 2 - dp
+            return torch.stack([a, dp * 0.7 + ip[:, 0] * 0.1], 1)
+    ev = types.SimpleNamespace(config=types.SimpleNamespace(n_classes=ncls),
+                               _normalize_dsm=lambda d: EV.Evaluator._normalize_dsm(None, d))
+    pred = EV.Evaluator._predict_image(ev, Standin(), img, dsm, 64, 10, (256, 256))
+    arrs["predict_600_700_argmax"] = pred.astype(np.uint8)
+    save("sliding", **arrs)
+
+
+def case_metrics():
+    """utils2.metrics on a synthetic prediction/label pair (needs sklearn)."""
+    import contextlib
+    import io
+    import utils2
+    rng_p = ((detfill.uniform("metrics/p", (5000,)) + 1) * 3).astype(np.int64).clip(0, 5)
+    rng_g = ((detfill.uniform("metrics/g", (5000,)) + 1) * 3).astype(np.int64).clip(0, 5)
+    rng_g[::3] = rng_p[::3]
+    with contextlib.redirect_stdout(io.StringIO()):
+        miou = utils2.metrics(rng_p, rng_g, label_values=["a", "b", "c", "d", "e", "f"])
+    save("metrics", miou=np.array(miou))
+
+
+CASES = dict(blocks=case_blocks, encoder=case_encoder, model_tiny=case_model_tiny,
+             model_vitb=case_model_vitb, sliding=case_sliding, metrics=case_metrics)
+
+if __name__ == "__main__":
+    want = sys.argv[1:] or list(CASES)
+    sys.argv = ["oracle", "-mod", "sam_lora"]
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    install_stubs()
+    sys.path.insert(0, REF)
+    enter_scratch()
+    os.makedirs(GOLD, exist_ok=True)
+    for c in want:
+        print(f"[{c}]")
+        CASES[c]()
