@@ -51,6 +51,7 @@ _SIGS = {
     "mfnet_gelu_bwd": [P, P, P, I64, P],
     "mfnet_add_bf16": [P, P, P, I64, P],
     "mfnet_bias_grad": [P, I64, P, I64, I64, P],
+    "mfnet_transpose_bf16": [P, I64, P, I64, I64, I64, P],
 }
 
 

@@ -191,14 +191,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[4 * ni + r] = acc[ni][mi][r];
+    if (p.out_pre) {   // value before activation / residual (GELU pre-activation, adapter input, ...)
+      u32x4_t w0, w1;
+      w0.x = pack_bf16x2(v[0], v[1]); w0.y = pack_bf16x2(v[2], v[3]); w0.z = pack_bf16x2(v[4], v[5]); w0.w = pack_bf16x2(v[6], v[7]);
+      w1.x = pack_bf16x2(v[8], v[9]); w1.y = pack_bf16x2(v[10], v[11]); w1.z = pack_bf16x2(v[12], v[13]); w1.w = pack_bf16x2(v[14], v[15]);
+      u32x4_t* dst = reinterpret_cast<u32x4_t*>(p.out_pre + m * p.ldpre + nb);
+      dst[0] = w0; dst[1] = w1;
+    }
     if (p.act == 1) {
-      if (p.out_pre) {
-        u32x4_t w0, w1;
-        w0.x = pack_bf16x2(v[0], v[1]); w0.y = pack_bf16x2(v[2], v[3]); w0.z = pack_bf16x2(v[4], v[5]); w0.w = pack_bf16x2(v[6], v[7]);
-        w1.x = pack_bf16x2(v[8], v[9]); w1.y = pack_bf16x2(v[10], v[11]); w1.z = pack_bf16x2(v[12], v[13]); w1.w = pack_bf16x2(v[14], v[15]);
-        u32x4_t* dst = reinterpret_cast<u32x4_t*>(p.out_pre + m * p.ldpre + nb);
-        dst[0] = w0; dst[1] = w1;
-      }
 #pragma unroll
       for (int i = 0; i < 16; ++i) v[i] = gelu_f(v[i]);
     } else if (p.act == 2) {
@@ -250,7 +250,7 @@ extern "C" int mfnet_gemm_bf16(const void* A, int64_t lda, const void* W, int64_
   MF_CHECK_ARG(out_dtype == MFNET_BF16 || out_dtype == MFNET_F32, "gemm_bf16: bad out dtype");
   MF_CHECK_ARG(act >= 0 && act <= 2, "gemm_bf16: bad act");
   MF_CHECK_ARG(act != 2 || (aux && ldaux >= N && ldaux % 8 == 0), "gemm_bf16: act=2 needs aux");
-  MF_CHECK_ARG(!out_pre || (act == 1 && ldpre >= N && ldpre % 8 == 0), "gemm_bf16: out_pre needs act=1");
+  MF_CHECK_ARG(!out_pre || (act != 2 && ldpre >= N && ldpre % 8 == 0), "gemm_bf16: bad out_pre");
   MF_CHECK_ARG(!residual || (ldres >= N && ldres % 4 == 0), "gemm_bf16: bad residual ld");
   if (U) {
     MF_CHECK_ARG(V && R > 0 && R <= GEMM_MAX_R && R % 4 == 0 && ldu >= R && ldu % 4 == 0, "gemm_bf16: bad low-rank args (R=%d)", R);

@@ -194,3 +194,29 @@ extern "C" int mfnet_lora_mix_bwd(const float* P, const float* a, const float* w
   MF_LAUNCH_CHECK("lora_mix_bwd");
   return MFNET_OK;
 }
+
+// ------------------------------------------------------------------------- bf16 transpose (zero-padded)
+// x [M, N] bf16 (ld) -> y [N, Mp] bf16 with Mp >= M; columns M..Mp-1 are zero. Operand prep for the
+// weight-gradient GEMM dW = dY^T X of the trainable adapters (adapter.py:13-14).
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ x, int64_t ld,
+                                                             bf16_t* __restrict__ y, int64_t M, int64_t N, int64_t Mp) {
+  __shared__ bf16_t tile[64][66];
+  const int64_t m0 = (int64_t)blockIdx.x * 64, n0 = (int64_t)blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int64_t m = m0 + r, n = n0 + tx;
+    tile[r][tx] = (m < M && n < N) ? x[m * ld + n] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int64_t n = n0 + r, m = m0 + tx;
+    if (n < N && m < Mp) y[n * Mp + m] = tile[tx][r];
+  }
+}
+extern "C" int mfnet_transpose_bf16(const void* x, int64_t ld, void* y, int64_t M, int64_t N, int64_t Mp, hipStream_t stream) {
+  MF_CHECK_ARG(x && y && M > 0 && N > 0 && Mp >= M && ld >= N, "transpose_bf16: bad args");
+  dim3 grid((unsigned)ceil_div64(Mp, 64), (unsigned)ceil_div64(N, 64));
+  hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, stream, (const bf16_t*)x, ld, (bf16_t*)y, M, N, Mp);
+  MF_LAUNCH_CHECK("transpose_bf16");
+  return MFNET_OK;
+}

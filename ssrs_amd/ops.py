@@ -291,3 +291,25 @@ def bias_grad(dy, out=None):
         out = torch.zeros(N, dtype=torch.float32, device=dy.device)
     call("mfnet_bias_grad", dy2.data_ptr(), ld, out.data_ptr(), M, N, _stream(dy))
     return out
+
+
+def add_bf16(a, b, out):
+    _chk(a, b, out)
+    assert a.is_contiguous() and b.is_contiguous() and out.is_contiguous()
+    call("mfnet_add_bf16", a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream(a))
+    return out
+
+
+def transpose_pad(x, mult=64):
+    """x [M,N] bf16 -> [N, Mp] bf16, Mp = M rounded up to `mult`, zero padded."""
+    _chk(x)
+    x2, M, N, ld = _rows2d(x)
+    Mp = (M + mult - 1) // mult * mult
+    y = torch.empty((N, Mp), dtype=torch.bfloat16, device=x.device)
+    call("mfnet_transpose_bf16", x2.data_ptr(), ld, y.data_ptr(), M, N, Mp, _stream(x))
+    return y
+
+
+def gemm_tn(dy, x):
+    """dW[n,k] = sum_m dy[m,n] x[m,k]  (fp32 [N,K]); both bf16 row-major with M leading."""
+    return gemm(transpose_pad(dy), transpose_pad(x), out_dtype=torch.float32)

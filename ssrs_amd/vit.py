@@ -1,0 +1,552 @@
+"""Host side of the multimodal SAM ViT encoder: nn.Modules that mirror the reference's interface
+(same class names, constructor arguments, parameter names and two-tensor forwards) and drive the
+gfx950 kernels of libmfnet_hip through `ssrs_amd.ops`.
+
+Reference interfaces mirrored (paths relative to /root/reference):
+  lora.Linear / lora.MergedLinear      medsam/models/common/loralib/layers.py:93-268
+  Adapter                              medsam/models/common/adapter.py:7-25
+  LayerNorm2d                          medsam/models/common/layer_norm.py:5-17
+  LoraBlock (+Attention, MLPBlock)     medsam/models/ImageEncoder/vit/lora_block.py:10-196
+  AdapterFusionBlock                   medsam/models/ImageEncoder/vit/adapter_fusionblock.py:12-198
+  ImageEncoderViT / PatchEmbed         medsam/models/sam/modeling/image_encoder.py:21-197
+
+MI355X-first layout: both modalities are stacked into ONE token matrix [2*B*T, D] (they share every
+frozen weight), the residual stream stays fp32, GEMM operands are bf16 with fp32 accumulation, and
+each residual branch (attention / MLP) is a single autograd node with a hand-written backward, so
+no N x N score tensor, padded window or fp32 weight copy ever reaches HBM.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple, Type
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+BF = torch.bfloat16
+
+# ---------------------------------------------------------------------------------------------
+# frozen-weight caches (bf16 copies / transposes, resized tables); rebuilt when a parameter is
+# re-loaded (load_state_dict bumps _version) or moved (data_ptr changes)
+# ---------------------------------------------------------------------------------------------
+_cache = {}
+
+
+def _cached(key, params, build):
+    sig = tuple((p.data_ptr(), p._version, p.device) for p in params)
+    hit = _cache.get(key)
+    if hit is not None and hit[0] == sig:
+        return hit[1]
+    with torch.no_grad():
+        val = build()
+    _cache[key] = (sig, val)
+    return val
+
+
+def w_bf16(p: torch.Tensor, tag="") -> torch.Tensor:
+    """bf16 copy of a frozen [N,K] weight."""
+    return _cached(("w", id(p), tag), (p,), lambda: ops.cast(p.detach().reshape(p.shape[0], -1).contiguous(), BF))
+
+
+def wT_bf16(p: torch.Tensor, tag="") -> torch.Tensor:
+    """bf16 copy of the transpose [K,N] of a frozen [N,K] weight (operand of the dgrad GEMM)."""
+    return _cached(("wT", id(p), tag), (p,),
+                   lambda: ops.cast(p.detach().reshape(p.shape[0], -1).t().contiguous(), BF))
+
+
+def _resize_rel(rel: torch.Tensor, need: int) -> torch.Tensor:
+    """get_rel_pos's table resize (lora_block.py:260-271): linear interpolation to 2*k-1 rows."""
+    if rel.shape[0] == need:
+        return rel
+    return F.interpolate(rel.t()[None], size=need, mode="linear")[0].t()
+
+
+def build_rel_table(rel_h: torch.Tensor, rel_w: torch.Tensor, kh: int, kw: int):
+    """-> (tbl [NT,hd] bf16, tblT [hd,NT] bf16, Lh, Lw): rows [0,Lh) the h table, [Lh,Lh+Lw) the w
+    table (both resized to 2k-1 rows), zero rows up to a multiple of 32."""
+    Lh, Lw = 2 * kh - 1, 2 * kw - 1
+    t = torch.cat([_resize_rel(rel_h.detach().float(), Lh), _resize_rel(rel_w.detach().float(), Lw)], 0)
+    NT = ((Lh + Lw + 31) // 32) * 32
+    full = torch.zeros(NT, t.shape[1], dtype=torch.float32, device=t.device)
+    full[:Lh + Lw] = t
+    return full.to(BF).contiguous(), full.t().contiguous().to(BF).contiguous(), Lh, Lw
+
+
+def _rel_tables(attn: nn.Module, kh: int, kw: int):
+    return _cached(("rel", id(attn), kh, kw), (attn.rel_h, attn.rel_w),
+                   lambda: build_rel_table(attn.rel_h, attn.rel_w, kh, kw))
+
+
+# ---------------------------------------------------------------------------------------------
+# forward/backward building blocks (plain functions on tensors; no autograd inside)
+# ---------------------------------------------------------------------------------------------
+def _down(x_bf, A_x, A_y, half):
+    """a[m] = x[m] @ A_g^T with the modality-specific A (rows [0,half) -> A_x, rest -> A_y)."""
+    r = A_x.shape[0]
+    a = torch.empty((x_bf.shape[0], r), dtype=torch.float32, device=x_bf.device)
+    ops.skinny_nt(x_bf[:half], A_x, out=a[:half])
+    ops.skinny_nt(x_bf[half:], A_y, out=a[half:])
+    return a
+
+
+def _tn_groups(y_bf, u, half, transposed, scale=1.0):
+    return (ops.skinny_tn(y_bf[:half], u[:half], transposed, scale),
+            ops.skinny_tn(y_bf[half:], u[half:], transposed, scale))
+
+
+def _attention(qkv, attn_mod, G, Sh, Sw, heads, ws):
+    kh, kw = (ws, ws) if ws > 0 else (Sh, Sw)
+    tbl, tblT, Lh, Lw = _rel_tables(attn_mod, kh, kw)
+    hd = qkv.shape[1] // (3 * heads)
+    o, lse = ops.attn_fwd(qkv, attn_mod.qkv.bias, tbl, G, Sh, Sw, heads, ws, Lh, Lw, hd ** -0.5)
+    return o, lse, (tbl, tblT, Lh, Lw)
+
+
+class _LoraAttnBranch(torch.autograd.Function):
+    """h -> h + proj(attn(qkv_lora(LN1(h))))  for the stacked token matrix (lora_block.py:64-82)."""
+
+    @staticmethod
+    def forward(ctx, h, blk, geom, Ax, Ay, Bx, By):
+        B, Sh, Sw, heads, ws = geom
+        attn = blk.attn
+        D = h.shape[-1]
+        M = h.numel() // D
+        half = M // 2
+        r = Ax.shape[0] // 2
+        h2 = h.reshape(M, D)
+        ln, mean, rstd = ops.layernorm_fwd(h2, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+        a = _down(ln, Ax, Ay, half)
+        V = torch.zeros((2, 3 * D, 2 * r), dtype=torch.float32, device=h.device)
+        for g, Bm in enumerate((Bx, By)):
+            V[g, :D, :r] = Bm[:D]
+            V[g, 2 * D:, r:] = Bm[D:]
+        qkv = ops.gemm(ln, w_bf16(attn.qkv.weight), bias=attn.qkv.bias, U=a, V=V, rows_per_group=half,
+                       n_groups=2, lr_scale=1.0 / r)
+        o, lse, tb = _attention(qkv, attn, 2 * B, Sh, Sw, heads, ws)
+        out = ops.gemm(o, w_bf16(attn.proj.weight), bias=attn.proj.bias, residual=h2, out_dtype=torch.float32)
+        ctx.save_for_backward(h2, mean, rstd, ln, a, V, qkv, o, lse, Ax, Ay)
+        ctx.blk, ctx.geom, ctx.tb = blk, geom, tb
+        return out.view(h.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        h2, mean, rstd, ln, a, V, qkv, o, lse, Ax, Ay = ctx.saved_tensors
+        blk, (B, Sh, Sw, heads, ws), (tbl, tblT, Lh, Lw) = ctx.blk, ctx.geom, ctx.tb
+        attn = blk.attn
+        M, D = h2.shape
+        half = M // 2
+        r = Ax.shape[0] // 2
+        hd = D // heads
+        d2 = dout.reshape(M, D).contiguous()
+        d_bf = ops.cast(d2, BF)
+        dO = ops.gemm(d_bf, wT_bf16(attn.proj.weight))
+        dqkv = ops.attn_bwd(qkv, attn.qkv.bias, tbl, tblT, o, dO, lse, 2 * B, Sh, Sw, heads, ws, Lh, Lw, hd ** -0.5)
+        s = 1.0 / r
+        da = torch.empty_like(a)
+        for g, sl in enumerate((slice(0, half), slice(half, M))):
+            ops.skinny_nt(dqkv[sl], V[g].t().contiguous(), scale=s, out=da[sl])
+        dVx, dVy = _tn_groups(dqkv, a, half, False, s)
+        dBx = torch.cat([dVx[:D, :r], dVx[2 * D:, r:]], 0)
+        dBy = torch.cat([dVy[:D, :r], dVy[2 * D:, r:]], 0)
+        dAx, dAy = _tn_groups(ln, da, half, True)
+        At = torch.stack([Ax.t(), Ay.t()]).contiguous()            # [2, D, 2r]
+        dln = ops.gemm(dqkv, wT_bf16(attn.qkv.weight), U=da, V=At, rows_per_group=half, n_groups=2)
+        dh, _ = ops.layernorm_bwd(dln, h2, mean, rstd, blk.norm1.weight, dres=d2)
+        return dh.view(dout.shape), None, None, dAx, dAy, dBx, dBy
+
+
+def _mix_linear_fwd(x_bf, lin, half, act, residual):
+    """lora.Linear forward on stacked rows: returns (out, pre|None, saved)."""
+    r = lin.lora_Ax.shape[0]
+    a = _down(x_bf, lin.lora_Ax, lin.lora_Ay, half)
+    U = ops.lora_mix_fwd(a, lin.lora_wx, lin.lora_wy)
+    V = torch.cat([lin.lora_Bx, lin.lora_By], 1).contiguous()      # [N, 2r]
+    if act:
+        out, pre = ops.gemm(x_bf, w_bf16(lin.weight), bias=lin.bias, U=U, V=V, act=1, want_pre=True)
+    else:
+        out = ops.gemm(x_bf, w_bf16(lin.weight), bias=lin.bias, U=U, V=V, residual=residual,
+                       out_dtype=torch.float32 if residual is not None else BF)
+        pre = None
+    return out, pre, (a, U, V)
+
+
+def _mix_linear_bwd(d_bf, x_bf, lin, saved, half, gelu_aux=None):
+    """-> (dx bf16, dAx, dAy, dBx, dBy, dwx, dwy). d_bf: grad of the layer output (bf16, after any
+    activation backward of the NEXT layer); gelu_aux: this layer's INPUT pre-activation if the input
+    was GELU(pre) (then dx is the grad w.r.t. pre)."""
+    a, U, V = saved
+    r = a.shape[1]
+    P = ops.skinny_nt(d_bf, V.t().contiguous())
+    da, dw = ops.lora_mix_bwd(P, a, lin.lora_wx, lin.lora_wy)
+    dV = ops.skinny_tn(d_bf, U, False)
+    dAx, dAy = _tn_groups(x_bf, da, half, True)
+    At = torch.stack([lin.lora_Ax.t(), lin.lora_Ay.t()]).contiguous()
+    dx = ops.gemm(d_bf, wT_bf16(lin.weight), U=da, V=At, rows_per_group=half, n_groups=2,
+                  act=2 if gelu_aux is not None else 0, aux=gelu_aux)
+    return dx, dAx, dAy, dV[:, :r].contiguous(), dV[:, r:].contiguous(), dw[0:1].clone(), dw[1:2].clone()
+
+
+class _LoraMlpBranch(torch.autograd.Function):
+    """h -> h + lin2(gelu(lin1(LN2(h))))  with the cross-modal LoRA mix (lora_block.py:83-85,104-108)."""
+
+    @staticmethod
+    def forward(ctx, h, blk, *params):
+        D = h.shape[-1]
+        M = h.numel() // D
+        half = M // 2
+        h2 = h.reshape(M, D)
+        ln, mean, rstd = ops.layernorm_fwd(h2, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+        act, pre, s1 = _mix_linear_fwd(ln, blk.mlp.lin1, half, True, None)
+        out, _, s2 = _mix_linear_fwd(act, blk.mlp.lin2, half, False, h2)
+        ctx.save_for_backward(h2, mean, rstd, ln, act, pre, *s1, *s2)
+        ctx.blk = blk
+        return out.view(h.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        h2, mean, rstd, ln, act, pre, a1, U1, V1, a2, U2, V2 = ctx.saved_tensors
+        blk = ctx.blk
+        M, D = h2.shape
+        half = M // 2
+        d2 = dout.reshape(M, D).contiguous()
+        d_bf = ops.cast(d2, BF)
+        dpre, dA2x, dA2y, dB2x, dB2y, dw2x, dw2y = _mix_linear_bwd(d_bf, act, blk.mlp.lin2, (a2, U2, V2), half, gelu_aux=pre)
+        dln, dA1x, dA1y, dB1x, dB1y, dw1x, dw1y = _mix_linear_bwd(dpre, ln, blk.mlp.lin1, (a1, U1, V1), half)
+        dh, _ = ops.layernorm_bwd(dln, h2, mean, rstd, blk.norm2.weight, dres=d2)
+        # order must match LoraBlock._mlp_params()
+        return (dh.view(dout.shape), None, dA1x, dA1y, dB1x, dB1y, dw1x, dw1y, dA2x, dA2y, dB2x, dB2y, dw2x, dw2y)
+
+
+class _Neck(torch.autograd.Function):
+    """frozen neck: 1x1 conv -> LayerNorm2d -> 3x3 conv -> LayerNorm2d on channels-last tokens
+    (image_encoder.py:104-120,142-143). h [G,Sh,Sw,D] fp32 -> [G,Sh,Sw,256] fp32."""
+
+    @staticmethod
+    def forward(ctx, h, enc):
+        G, Sh, Sw, D = h.shape
+        M = G * Sh * Sw
+        neck = enc.neck
+        C = neck[0].weight.shape[0]
+        hb = ops.cast(h.reshape(M, D).contiguous(), BF)
+        n1 = ops.gemm(hb, w_bf16(neck[0].weight), out_dtype=torch.float32)
+        l1, m1, r1 = ops.layernorm_fwd(n1, neck[1].weight, neck[1].bias, neck[1].eps)
+        cols = ops.im2col3x3(l1, G, Sh, Sw)
+        n2 = ops.gemm(cols, _neck3x3_w(neck[2].weight), out_dtype=torch.float32)
+        out, m3, r3 = ops.layernorm_fwd(n2, neck[3].weight, neck[3].bias, neck[3].eps, out_dtype=torch.float32)
+        ctx.save_for_backward(n1, m1, r1, n2, m3, r3)
+        ctx.enc, ctx.shape = enc, (G, Sh, Sw, D, C)
+        return out.view(G, Sh, Sw, C)
+
+    @staticmethod
+    def backward(ctx, dout):
+        n1, m1, r1, n2, m3, r3 = ctx.saved_tensors
+        G, Sh, Sw, D, C = ctx.shape
+        neck = ctx.enc.neck
+        M = G * Sh * Sw
+        _, dn2 = ops.layernorm_bwd(dout.reshape(M, C).contiguous(), n2, m3, r3, neck[3].weight, want_f32=False, want_bf16=True)
+        dcols = ops.gemm(dn2, _neck3x3_wT(neck[2].weight))
+        dl1 = ops.col2im3x3(dcols, G, Sh, Sw, C)
+        _, dn1 = ops.layernorm_bwd(dl1, n1, m1, r1, neck[1].weight, want_f32=False, want_bf16=True)
+        dh = ops.gemm(dn1, wT_bf16(neck[0].weight), out_dtype=torch.float32)
+        return dh.view(G, Sh, Sw, D), None
+
+
+def _neck3x3_w(w):     # [O, I, 3, 3] -> [O, 9*I] with k = tap*I + c  (im2col3x3 order)
+    return _cached(("n3", id(w)), (w,), lambda: ops.cast(w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous(), BF))
+
+
+def _neck3x3_wT(w):
+    return _cached(("n3T", id(w)), (w,), lambda: ops.cast(w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).t().contiguous(), BF))
+
+
+# ---------------------------------------------------------------------------------------------
+# loralib layers (two-tensor forward, loralib/layers.py)
+# ---------------------------------------------------------------------------------------------
+class LoRALayer:
+    def __init__(self, r: int, lora_alpha: int, lora_dropout: float, merge_weights: bool):
+        if lora_dropout and lora_dropout > 0.0:
+            raise NotImplementedError("lora_dropout > 0 is never used by MFNet and is not implemented")
+        self.r = r
+        self.lora_alpha = lora_alpha
+        self.lora_dropout = lambda x: x
+        self.merged = False
+        self.merge_weights = merge_weights
+
+
+def _check_rank(r):
+    if r not in (2, 4, 8):
+        raise ValueError(f"LoRA rank {r} unsupported by the HIP path (use 2, 4 or 8; default 4)")
+
+
+class Linear(nn.Linear, LoRALayer):
+    """lora.Linear (loralib/layers.py:93-167): dense layer shared by both modalities plus a
+    per-modality rank-r update, cross-mixed by the trainable scalars lora_wx / lora_wy."""
+
+    def __init__(self, in_features, out_features, r=0, lora_alpha=1, lora_dropout=0.0, fan_in_fan_out=False,
+                 merge_weights=True, **kwargs):
+        nn.Linear.__init__(self, in_features, out_features, **kwargs)
+        LoRALayer.__init__(self, r=r, lora_alpha=lora_alpha, lora_dropout=lora_dropout, merge_weights=merge_weights)
+        if fan_in_fan_out:
+            raise NotImplementedError("fan_in_fan_out is unused by MFNet")
+        self.fan_in_fan_out = False
+        if r > 0:
+            _check_rank(r)
+            self.lora_Ax = nn.Parameter(self.weight.new_zeros((r, in_features)))
+            self.lora_Ay = nn.Parameter(self.weight.new_zeros((r, in_features)))
+            self.lora_Bx = nn.Parameter(self.weight.new_zeros((out_features, r)))
+            self.lora_By = nn.Parameter(self.weight.new_zeros((out_features, r)))
+            self.scaling = self.lora_alpha / self.r
+            self.weight.requires_grad = False
+            for a in (self.lora_Ax, self.lora_Ay):
+                nn.init.kaiming_uniform_(a, a=math.sqrt(5))
+        self.lora_wx = nn.Parameter(torch.full((1,), 0.5))
+        self.lora_wy = nn.Parameter(torch.full((1,), 0.5))
+
+    def forward(self, x: torch.Tensor, y: torch.Tensor):
+        h = torch.stack([x, y])
+        out = _StandaloneMixLinear.apply(h, self, self.lora_Ax, self.lora_Ay, self.lora_Bx, self.lora_By,
+                                         self.lora_wx, self.lora_wy)
+        return out[0], out[1]
+
+
+class _StandaloneMixLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, lin, *params):
+        K = h.shape[-1]
+        M = h.numel() // K
+        xb = ops.cast(h.reshape(M, K).contiguous().float(), BF)
+        out, _, saved = _mix_linear_fwd(xb, lin, M // 2, False, None)
+        ctx.save_for_backward(xb, *saved)
+        ctx.lin = lin
+        return out.float().view(*h.shape[:-1], -1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xb, a, U, V = ctx.saved_tensors
+        N = dout.shape[-1]
+        M = dout.numel() // N
+        d_bf = ops.cast(dout.reshape(M, N).contiguous(), BF)
+        dx, dAx, dAy, dBx, dBy, dwx, dwy = _mix_linear_bwd(d_bf, xb, ctx.lin, (a, U, V), M // 2)
+        return dx.float().view(*dout.shape[:-1], -1), None, dAx, dAy, dBx, dBy, dwx, dwy
+
+
+class MergedLinear(nn.Linear, LoRALayer):
+    """lora.MergedLinear (loralib/layers.py:169-268) with enable_lora=[True, False, True]."""
+
+    def __init__(self, in_features, out_features, r=0, lora_alpha=1, lora_dropout=0.0, enable_lora=(False,),
+                 fan_in_fan_out=False, merge_weights=True, **kwargs):
+        nn.Linear.__init__(self, in_features, out_features, **kwargs)
+        LoRALayer.__init__(self, r=r, lora_alpha=lora_alpha, lora_dropout=lora_dropout, merge_weights=merge_weights)
+        enable_lora = list(enable_lora)
+        assert out_features % len(enable_lora) == 0, "The length of enable_lora must divide out_features"
+        if fan_in_fan_out:
+            raise NotImplementedError("fan_in_fan_out is unused by MFNet")
+        if r > 0 and enable_lora != [True, False, True]:
+            raise NotImplementedError("the HIP path implements enable_lora=[True, False, True] (q and v), as MFNet uses")
+        self.enable_lora = enable_lora
+        self.fan_in_fan_out = False
+        if r > 0:
+            _check_rank(r)
+            n = sum(enable_lora)
+            per = out_features // len(enable_lora)
+            self.lora_Ax = nn.Parameter(self.weight.new_zeros((r * n, in_features)))
+            self.lora_Bx = nn.Parameter(self.weight.new_zeros((per * n, r)))
+            self.lora_Ay = nn.Parameter(self.weight.new_zeros((r * n, in_features)))
+            self.lora_By = nn.Parameter(self.weight.new_zeros((per * n, r)))
+            self.scaling = self.lora_alpha / self.r
+            self.weight.requires_grad = False
+            ind = self.weight.new_zeros((out_features,), dtype=torch.bool).view(len(enable_lora), -1)
+            ind[enable_lora, :] = True
+            self.lora_ind = ind.view(-1)
+            for a in (self.lora_Ax, self.lora_Ay):
+                nn.init.kaiming_uniform_(a, a=math.sqrt(5))
+
+
+class Adapter(nn.Module):
+    """common/adapter.py:7-25."""
+
+    def __init__(self, D_features, mlp_ratio=0.25, act_layer=nn.GELU, skip_connect=True):
+        super().__init__()
+        self.skip_connect = skip_connect
+        D_hidden = int(D_features * mlp_ratio)
+        self.act = act_layer()
+        self.D_fc1 = nn.Linear(D_features, D_hidden)
+        self.D_fc2 = nn.Linear(D_hidden, D_features)
+
+
+class LayerNorm2d(nn.Module):
+    """common/layer_norm.py:5-17 (NCHW interface; computed channels-last by the LayerNorm kernel)."""
+
+    def __init__(self, num_channels: int, eps: float = 1e-6) -> None:
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(num_channels))
+        self.bias = nn.Parameter(torch.zeros(num_channels))
+        self.eps = eps
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        from .decoder_ops import layer_norm_nhwc
+        return layer_norm_nhwc(x.permute(0, 2, 3, 1).contiguous(), self.weight, self.bias, self.eps).permute(0, 3, 1, 2)
+
+
+# ---------------------------------------------------------------------------------------------
+# blocks
+# ---------------------------------------------------------------------------------------------
+class MLPBlock(nn.Module):
+    def __init__(self, embedding_dim: int, mlp_dim: int, act: Type[nn.Module] = nn.GELU, lora_rank: int = 4) -> None:
+        super().__init__()
+        self.lin1 = Linear(embedding_dim, mlp_dim, r=lora_rank)
+        self.lin2 = Linear(mlp_dim, embedding_dim, r=lora_rank)
+        self.act = act()
+
+
+class Attention(nn.Module):
+    """LoRA attention (lora_block.py:111-196): parameter container; compute is in _LoraAttnBranch."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=True, use_rel_pos=False, rel_pos_zero_init=True,
+                 lora_rank=4, input_size: Optional[Tuple[int, int]] = None) -> None:
+        super().__init__()
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = head_dim ** -0.5
+        self.qkv = MergedLinear(dim, dim * 3, bias=qkv_bias, r=lora_rank, enable_lora=[True, False, True])
+        self.proj = nn.Linear(dim, dim)
+        self.use_rel_pos = use_rel_pos
+        if self.use_rel_pos:
+            assert input_size is not None, "Input size must be provided if using relative positional encoding."
+            self.rel_h = nn.Parameter(torch.zeros(2 * input_size[0] - 1, head_dim))
+            self.rel_w = nn.Parameter(torch.zeros(2 * input_size[1] - 1, head_dim))
+        else:
+            raise NotImplementedError("MFNet always builds SAM with use_rel_pos=True (build_sam.py:84)")
+
+
+def _geom(h, heads, ws):
+    _, B, Sh, Sw, _ = h.shape
+    return (B, Sh, Sw, heads, ws)
+
+
+class LoraBlock(nn.Module):
+    """lora_block.py:10-87. forward(x, y) keeps the reference's two-tensor interface; the encoder
+    calls forward_stacked on the [2,B,H,W,C] residual stream directly."""
+
+    def __init__(self, args, dim, num_heads, mlp_ratio=4.0, qkv_bias=True, norm_layer=nn.LayerNorm,
+                 act_layer=nn.GELU, use_rel_pos=False, rel_pos_zero_init=True, window_size=0,
+                 input_size: Optional[Tuple[int, int]] = None) -> None:
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        lora_rank = args.mid_dim if args.mid_dim is not None else 4
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, use_rel_pos=use_rel_pos,
+                              rel_pos_zero_init=rel_pos_zero_init, lora_rank=lora_rank,
+                              input_size=(64, 64) if window_size == 0 else (window_size, window_size))
+        self.norm2 = norm_layer(dim)
+        self.mlp = MLPBlock(embedding_dim=dim, mlp_dim=int(dim * mlp_ratio), act=act_layer, lora_rank=lora_rank)
+        self.window_size = window_size
+        self.num_heads = num_heads
+
+    def _mlp_params(self):
+        l1, l2 = self.mlp.lin1, self.mlp.lin2
+        return (l1.lora_Ax, l1.lora_Ay, l1.lora_Bx, l1.lora_By, l1.lora_wx, l1.lora_wy,
+                l2.lora_Ax, l2.lora_Ay, l2.lora_Bx, l2.lora_By, l2.lora_wx, l2.lora_wy)
+
+    def forward_stacked(self, h: torch.Tensor) -> torch.Tensor:
+        q = self.attn.qkv
+        h = _LoraAttnBranch.apply(h, self, _geom(h, self.num_heads, self.window_size),
+                                  q.lora_Ax, q.lora_Ay, q.lora_Bx, q.lora_By)
+        return _LoraMlpBranch.apply(h, self, *self._mlp_params())
+
+    def forward(self, x: torch.Tensor, y: torch.Tensor):
+        h = self.forward_stacked(torch.stack([x, y]).float().contiguous())
+        return h[0], h[1]
+
+
+class PatchEmbed(nn.Module):
+    """image_encoder.py:166-197 (parameter container; the im2col GEMM runs in ImageEncoderViT)."""
+
+    def __init__(self, kernel_size=(16, 16), stride=(16, 16), padding=(0, 0), in_chans=3, embed_dim=768) -> None:
+        super().__init__()
+        assert tuple(kernel_size) == tuple(stride) and tuple(padding) == (0, 0) and in_chans == 3
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=kernel_size, stride=stride, padding=padding)
+
+
+class ImageEncoderViT(nn.Module):
+    """image_encoder.py:21-144: forward(x, y) -> (fx, fy), each (B, out_chans, H/16, W/16)."""
+
+    def __init__(self, args, img_size=1024, patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=12,
+                 mlp_ratio=4.0, out_chans=256, qkv_bias=True, norm_layer=nn.LayerNorm, act_layer=nn.GELU,
+                 use_abs_pos=True, use_rel_pos=False, rel_pos_zero_init=True, window_size=0,
+                 global_attn_indexes=()) -> None:
+        super().__init__()
+        self.img_size = img_size
+        self.args = args
+        self.embed_dim = embed_dim
+        self.patch_size = patch_size
+        self.patch_embed = PatchEmbed(kernel_size=(patch_size, patch_size), stride=(patch_size, patch_size),
+                                      in_chans=in_chans, embed_dim=embed_dim)
+        self.pos_embed = None
+        if use_abs_pos:
+            self.pos_embed = nn.Parameter(torch.zeros(1, 1024 // patch_size, 1024 // patch_size, embed_dim))
+        if args.mod == "sam_adpt":
+            from .vit_adapter import AdapterFusionBlock
+            block_class = AdapterFusionBlock
+        elif args.mod == "sam_lora":
+            block_class = LoraBlock
+        else:
+            raise NotImplementedError(f"mod={args.mod!r}: the HIP path implements 'sam_lora' (MMLoRA) and "
+                                      "'sam_adpt' (MMAdapter), the two dual-modality variants MFNet can run")
+        self.blocks = nn.ModuleList()
+        for i in range(depth):
+            self.blocks.append(block_class(
+                args=args, dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                norm_layer=norm_layer, act_layer=act_layer, use_rel_pos=use_rel_pos,
+                rel_pos_zero_init=rel_pos_zero_init,
+                window_size=window_size if i not in global_attn_indexes else 0,
+                input_size=(img_size // patch_size, img_size // patch_size)))
+        self.neck = nn.Sequential(
+            nn.Conv2d(embed_dim, out_chans, kernel_size=1, bias=False), LayerNorm2d(out_chans),
+            nn.Conv2d(out_chans, out_chans, kernel_size=3, padding=1, bias=False), LayerNorm2d(out_chans))
+
+    def _pos(self, Sh, Sw):
+        """abs-pos-embed bicubically resized to the token grid (image_encoder.py:126-135); frozen, so
+        computed once per grid size and cached as a [T, D] fp32 matrix."""
+        p = self.pos_embed
+        return _cached(("pos", id(p), Sh, Sw), (p,), lambda: F.interpolate(
+            p.detach().permute(0, 3, 1, 2), size=(Sh, Sw), mode="bicubic", align_corners=False
+        ).permute(0, 2, 3, 1).reshape(Sh * Sw, -1).contiguous())
+
+    def embed(self, rgb: torch.Tensor, dsm: torch.Tensor) -> torch.Tensor:
+        """patch-embed both modalities (DSM replicated to 3 channels by the im2col) + abs-pos add
+        -> stacked residual stream [2, B, Sh, Sw, D] fp32."""
+        B, _, H, W = rgb.shape
+        P = self.patch_size
+        Sh, Sw = H // P, W // P
+        with torch.no_grad():
+            cols = ops.im2col_patch(rgb.float().contiguous(), dsm.float().contiguous(), P)
+            pe = self.patch_embed.proj
+            if self.pos_embed is not None:
+                h = ops.gemm(cols, w_bf16(pe.weight), bias=pe.bias, residual=self._pos(Sh, Sw), res_row_mod=Sh * Sw,
+                             out_dtype=torch.float32)
+            else:
+                h = ops.gemm(cols, w_bf16(pe.weight), bias=pe.bias, out_dtype=torch.float32)
+        return h.view(2, B, Sh, Sw, -1)
+
+    def forward_stacked(self, rgb, dsm):
+        h = self.embed(rgb, dsm)
+        for blk in self.blocks:
+            h = blk.forward_stacked(h)
+        two, B, Sh, Sw, D = h.shape
+        return _Neck.apply(h.view(2 * B, Sh, Sw, D), self)          # [2B, Sh, Sw, C] channels-last
+
+    def forward(self, x: torch.Tensor, y: torch.Tensor):
+        """x, y: (B,3,H,W). The reference feeds y = DSM repeated to 3 channels (unetformer_mmsam.py:535);
+        the shared patch-embed is linear, so a general 3-channel y is handled by the same kernel only
+        when its channels are identical - otherwise it is embedded as a second RGB batch."""
+        B = x.shape[0]
+        if y.dim() == 4 and bool((y[:, :1] == y).all()):
+            out = self.forward_stacked(x, y[:, 0])
+        else:
+            raise NotImplementedError("ImageEncoderViT.forward needs y = a single channel repeated 3x (the DSM/NIR "
+                                      "modality as MFNet feeds it); pass the (B,H,W) plane via forward_stacked")
+        fx, fy = out[:B], out[B:]
+        return fx.permute(0, 3, 1, 2), fy.permute(0, 3, 1, 2)

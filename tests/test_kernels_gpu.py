@@ -1,0 +1,284 @@
+"""Per-kernel parity on the GPU: HIP kernel (through the C ABI) vs a plain fp32/fp64 PyTorch
+restatement of the same op on the SAME bf16-rounded inputs. Tolerances: fp32 accumulate over bf16
+inputs -> 2e-3 relative on bf16 outputs (one bf16 rounding), 1e-4..1e-5 on fp32 outputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import bf16r, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from ssrs_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1).mul_(scale).cuda()
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("rows,C", [(8192, 768), (1000, 256), (37, 128), (512, 1280)])
+def test_layernorm_fwd_bwd(ops, rows, C):
+    x = rnd(rows, C, seed=1, scale=3.0) + 0.5
+    g = 1 + 0.1 * rnd(C, seed=2)
+    b = 0.1 * rnd(C, seed=3)
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6, out_dtype=torch.float32)
+    ref = F.layer_norm(x.double(), (C,), g.double(), b.double(), 1e-6)
+    assert rel_err(y, ref) < 1e-5
+    yb, _, _ = ops.layernorm_fwd(x, g, b, 1e-6, out_dtype=torch.bfloat16)
+    assert rel_err(yb.float(), ref) < 5e-3
+    # backward (fp32 dy and bf16 dy), with residual-gradient add and weight grads
+    dy = rnd(rows, C, seed=4)
+    dres = rnd(rows, C, seed=5)
+    xd = x.double().requires_grad_()
+    gd = g.double().requires_grad_()
+    bd = b.double().requires_grad_()
+    F.layer_norm(xd, (C,), gd, bd, 1e-6).backward(dy.double())
+    dg = torch.zeros(C, device="cuda")
+    db = torch.zeros(C, device="cuda")
+    dx, dxb = ops.layernorm_bwd(dy, x, mean, rstd, g, dres=dres, want_f32=True, want_bf16=True, dgamma=dg, dbeta=db)
+    assert rel_err(dx, xd.grad + dres.double()) < 2e-5
+    assert rel_err(dxb.float(), xd.grad + dres.double()) < 5e-3
+    assert rel_err(dg, gd.grad) < 1e-4 and rel_err(db, bd.grad) < 1e-4
+    dyb = dy.to(torch.bfloat16)
+    dx2, _ = ops.layernorm_bwd(dyb, x, mean, rstd, g)
+    xd.grad = None
+    F.layer_norm(xd, (C,), gd, bd, 1e-6).backward(dyb.double())
+    assert rel_err(dx2, xd.grad) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(8192, 768, 768), (1024, 2304, 768), (512, 768, 3072), (800, 192, 768),
+                                   (333, 256, 2304), (128, 128, 64), (5000, 3072, 768)])
+def test_gemm_plain(ops, M, N, K):
+    a = rnd(M, K, seed=1).to(torch.bfloat16)
+    w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+    bias = rnd(N, seed=3)
+    ref = a.double() @ w.double().t() + bias.double()
+    out = ops.gemm(a, w, bias=bias, out_dtype=torch.float32)
+    assert rel_err(out, ref) < 1e-5
+    outb = ops.gemm(a, w, bias=bias, out_dtype=torch.bfloat16)
+    assert rel_err(outb.float(), ref) < 5e-3
+
+
+def test_gemm_identity_asymmetric(ops):
+    """A = I with an asymmetric W catches a transposed / permuted C-write (guide section 3)."""
+    K = N = 256
+    a = torch.eye(K, device="cuda").to(torch.bfloat16)
+    w = (torch.arange(N * K, device="cuda").reshape(N, K) % 251).float().to(torch.bfloat16)
+    out = ops.gemm(a, w, out_dtype=torch.float32)
+    assert torch.equal(out, w.float().t().contiguous())
+
+
+@pytest.mark.parametrize("R,G", [(8, 1), (8, 2), (4, 2), (16, 1)])
+def test_gemm_lowrank_gelu_residual(ops, R, G):
+    M, N, K = 1024, 768, 768
+    a = rnd(M, K, seed=1).to(torch.bfloat16)
+    w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+    bias = rnd(N, seed=3)
+    U = rnd(M, R, seed=4)
+    V = rnd(G, N, R, seed=5)
+    res = rnd(M, N, seed=6)
+    rpg = M // G
+    lr = 0.25
+    low = torch.cat([U[g * rpg:(g + 1) * rpg].double() @ V[g].double().t() for g in range(G)]) * lr
+    pre_ref = a.double() @ w.double().t() + bias.double() + low
+    # act=1 (GELU) with pre-activation output, bf16 out
+    out, pre = ops.gemm(a, w, bias=bias, U=U, V=V, rows_per_group=rpg, n_groups=G, lr_scale=lr, act=1, want_pre=True)
+    assert rel_err(pre.float(), pre_ref) < 5e-3
+    assert rel_err(out.float(), F.gelu(pre_ref)) < 5e-3
+    # residual add into fp32 (in place: residual aliases out)
+    out2 = res.clone()
+    ops.gemm(a, w, bias=bias, U=U, V=V, rows_per_group=rpg, n_groups=G, lr_scale=lr, residual=out2, out=out2)
+    assert rel_err(out2, pre_ref + res.double()) < 1e-5
+    # act=2: multiply by gelu'(aux)
+    aux = rnd(M, N, seed=7, scale=2.0).to(torch.bfloat16)
+    ad = aux.double().requires_grad_()
+    F.gelu(ad).sum().backward()
+    out3 = ops.gemm(a, w, act=2, aux=aux, out_dtype=torch.float32)
+    assert rel_err(out3, (a.double() @ w.double().t()) * ad.grad) < 2e-5
+    # broadcast residual rows (pos-embed add): residual row = m % mod
+    pos = rnd(256, N, seed=8)
+    out4 = ops.gemm(a, w, residual=pos, res_row_mod=256, out_dtype=torch.float32)
+    assert rel_err(out4, a.double() @ w.double().t() + pos.double().repeat(M // 256, 1)) < 1e-5
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    from ssrs_amd._lib import MfnetError
+    a = torch.zeros(64, 100, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(64, 100, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(MfnetError):
+        ops.gemm(a, w)
+    with pytest.raises(MfnetError):
+        ops.gemm(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(16, 64, dtype=torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------------------ skinny / lora
+@pytest.mark.parametrize("M,K,R", [(8192, 768, 8), (4100, 3072, 4), (100, 128, 16)])
+def test_skinny(ops, M, K, R):
+    x = rnd(M, K, seed=1).to(torch.bfloat16)
+    wt = rnd(R, K, seed=2)
+    out = ops.skinny_nt(x, wt, scale=0.5)
+    assert rel_err(out, 0.5 * (x.double() @ wt.double().t())) < 1e-5
+    u = rnd(M, R, seed=3)
+    for tr in (False, True):
+        o = ops.skinny_tn(x, u, transposed=tr, scale=2.0)
+        ref = 2.0 * (x.double().t() @ u.double())
+        assert rel_err(o, ref.t() if tr else ref) < 1e-4
+
+
+def test_lora_mix(ops):
+    M, r = 2048, 4
+    a = rnd(M, r, seed=1)
+    wx = torch.tensor([0.37], device="cuda")
+    wy = torch.tensor([0.81], device="cuda")
+    U = ops.lora_mix_fwd(a, wx, wy)
+    ax, ay = a[:M // 2], a[M // 2:]
+    ref = torch.cat([torch.cat([wx * ax, (1 - wx) * ay], 1), torch.cat([(1 - wy) * ax, wy * ay], 1)])
+    assert rel_err(U, ref) < 1e-6
+    P = rnd(M, 2 * r, seed=2)
+    ad = a.double().requires_grad_()
+    wxd = wx.double().requires_grad_()
+    wyd = wy.double().requires_grad_()
+    axd, ayd = ad[:M // 2], ad[M // 2:]
+    Ud = torch.cat([torch.cat([wxd * axd, (1 - wxd) * ayd], 1), torch.cat([(1 - wyd) * axd, wyd * ayd], 1)])
+    (Ud * P.double()).sum().backward()
+    da, dw = ops.lora_mix_bwd(P, a, wx, wy)
+    assert rel_err(da, ad.grad) < 1e-5
+    assert rel_err(dw, torch.stack([wxd.grad[0], wyd.grad[0]])) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ im2col
+def test_im2col_patch_and_3x3(ops):
+    B, H, W = 2, 64, 96
+    rgb = rnd(B, 3, H, W, seed=1)
+    dsm = rnd(B, H, W, seed=2)
+    cols = ops.im2col_patch(rgb, dsm, 16)
+    both = torch.cat([rgb, dsm[:, None].repeat(1, 3, 1, 1)])
+    ref = F.unfold(both, 16, stride=16).transpose(1, 2).reshape(-1, 768)
+    assert torch.equal(cols.float(), bf16r(ref))
+    G, S, C = 3, 10, 64
+    x = rnd(G, S, S, C, seed=3).to(torch.bfloat16)
+    c3 = ops.im2col3x3(x, G, S, S)
+    xr = x.float().permute(0, 3, 1, 2)
+    ref3 = F.unfold(xr, 3, padding=1).view(G, C, 9, S * S).permute(0, 3, 2, 1).reshape(G * S * S, 9 * C)
+    assert torch.equal(c3.float(), ref3)
+    dc = rnd(G * S * S, 9 * C, seed=4).to(torch.bfloat16)
+    dx = ops.col2im3x3(dc, G, S, S, C)
+    refdx = F.fold(dc.float().view(G, S * S, 9, C).permute(0, 3, 2, 1).reshape(G, C * 9, S * S), (S, S), 3, padding=1)
+    assert rel_err(dx.view(G, S, S, C), refdx.permute(0, 2, 3, 1)) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _attn_reference(qkv, bias, rel_h, rel_w, G, S, heads, ws):
+    """fp64 restatement through the oracle's window/rel-pos functions: padded tokens carry qkv = bias."""
+    from oracle import mfnet_ref as R
+    D = qkv.shape[1] // 3
+    hd = D // heads
+    t = qkv.view(G, S, S, 3 * D)
+    if ws > 0:
+        pad = (ws - S % ws) % ws
+        tp = bias.view(1, 1, 1, -1).expand(G, S + pad, S + pad, 3 * D).clone()
+        tp[:, :S, :S] = t
+        Hp = S + pad
+        win = tp.view(G, Hp // ws, ws, Hp // ws, ws, 3 * D).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, 3 * D)
+        h = w = ws
+    else:
+        win = t.reshape(G, S * S, 3 * D)
+        h = w = S
+    q, k, v = R.split_heads(win, heads)
+    o = R.attention_core(q, k, v, rel_h, rel_w, (h, w), hd ** -0.5)
+    o = R.merge_heads(o, win.shape[0], heads, h, w)
+    if ws > 0:
+        o = R.window_unpartition(o, ws, (Hp, Hp), (S, S))
+    return o.reshape(G * S * S, D)
+
+
+def _rel_tables(rel_h, rel_w, k):
+    """[rel_h ; rel_w] resized to 2k-1 rows each, zero-padded to a multiple of 32 rows (bf16)."""
+    from ssrs_amd.vit import build_rel_table
+    return build_rel_table(rel_h, rel_w, k, k)
+
+
+@pytest.mark.parametrize("S,ws,heads,G", [(16, 14, 2, 2), (16, 0, 2, 2), (20, 14, 3, 1), (20, 0, 1, 2), (16, 14, 12, 4)])
+def test_attention_fwd_bwd(ops, S, ws, heads, G):
+    D = heads * 64
+    qkv = rnd(G * S * S, 3 * D, seed=1, scale=1.5).to(torch.bfloat16)
+    bias = rnd(3 * D, seed=2)
+    L = 27 if ws > 0 else 127
+    rel_h = rnd(L, 64, seed=3, scale=0.2)
+    rel_w = rnd(L, 64, seed=4, scale=0.2)
+    k = ws if ws > 0 else S
+    tbl, tblT, Lh, Lw = _rel_tables(rel_h, rel_w, k)
+    out, lse = ops.attn_fwd(qkv, bias, tbl, G, S, S, heads, ws, Lh, Lw, 64 ** -0.5)
+    # reference on the same rounded operands (bf16 tables, bf16 padded-key bias), fp64
+    rh = tbl[:Lh].double().cpu()
+    rw = tbl[Lh:Lh + Lw].double().cpu()
+    qd = qkv.double().cpu().requires_grad_()
+    ref = _attn_reference(qd, bf16r(bias).double().cpu(), rh, rw, G, S, heads, ws)
+    assert rel_err(out.float(), ref.detach()) < 1e-2
+    dout = rnd(G * S * S, D, seed=5).to(torch.bfloat16)
+    ref.backward(dout.double().cpu())
+    dqkv = ops.attn_bwd(qkv, bias, tbl, tblT, out, dout, lse, G, S, S, heads, ws, Lh, Lw, 64 ** -0.5)
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        e = rel_err(dqkv[:, sl].float(), qd.grad[:, sl])
+        assert e < 2e-2, (name, e)
+
+
+# ------------------------------------------------------------------------------------------ loss / sgd / merge
+@pytest.mark.parametrize("C,ignore", [(6, -100), (2, 255)])
+def test_ce_loss(ops, C, ignore):
+    B, H, W = 3, 64, 80
+    logits = rnd(B, C, H, W, seed=1, scale=4.0)
+    tgt = torch.randint(0, C, (B, H, W), generator=torch.Generator().manual_seed(2)).cuda()
+    if ignore == 255:
+        tgt[:, :10, :20] = 255
+    wt = (1 + 0.5 * rnd(C, seed=3)) if ignore != 255 else None
+    acc, pred = ops.ce_loss_fwd(logits, tgt, wt, ignore, want_pred=True)
+    ld = logits.double().requires_grad_()
+    ref = F.cross_entropy(ld.permute(0, 2, 3, 1).reshape(-1, C), tgt.view(-1),
+                          wt.double() if wt is not None else None, ignore_index=ignore)
+    ref.backward()
+    assert abs((acc[0] / acc[1]).item() - ref.item()) < 1e-5 * max(1, abs(ref.item()))
+    assert torch.equal(pred.long(), logits.argmax(1))
+    d = ops.ce_loss_bwd(logits, tgt, acc, wt, ignore, gscale=1.0)
+    assert rel_err(d, ld.grad) < 1e-4
+
+
+def test_sgd_flat(ops):
+    n = 100003
+    p = rnd(n, seed=1)
+    g = rnd(n, seed=2)
+    pr = torch.nn.Parameter(p.clone())
+    opt = torch.optim.SGD([pr], lr=0.01, momentum=0.9, weight_decay=5e-4)
+    buf = torch.zeros_like(p)
+    for step in range(3):
+        pr.grad = g.clone() * (step + 1)
+        opt.step()
+        ops.sgd_flat(p, g * (step + 1), buf, 0.01, 0.9, 5e-4)
+    assert rel_err(p, pr.data) < 1e-6
+
+
+def test_tile_accumulate_argmax_minmax(ops):
+    C, H, W, h, w = 3, 300, 280, 64, 64
+    pred = torch.zeros(C, H, W, device="cuda")
+    coords = torch.tensor([[0, 0], [32, 16], [236, 216], [236, 216], [100, 100]], dtype=torch.int32, device="cuda")
+    logits = rnd(5, C, h, w, seed=1)
+    ops.tile_accumulate(pred, logits, coords, atomic=True)
+    ref = torch.zeros(C, H, W, dtype=torch.float64)
+    for i, (x, y) in enumerate(coords.tolist()):
+        ref[:, x:x + h, y:y + w] += logits[i].double().cpu()
+    assert rel_err(pred, ref) < 1e-6
+    assert torch.equal(ops.argmax_chw(pred).long().cpu(), pred.cpu().argmax(0))
+    x = rnd(1000, 999, seed=3, scale=50.0) + 7
+    mm = ops.minmax(x)
+    assert mm[0].item() == x.min().item() and mm[1].item() == x.max().item()
+    y = ops.scale_shift(x, mm, 0)
+    assert rel_err(y, (x - x.min()) / (x.max() - x.min())) < 1e-6

@@ -146,7 +146,8 @@ def case_encoder():
         enc.load_state_dict(detfill.fill_state_dict(enc.state_dict(), tag + "/"))
         enc.eval()
         x = torch.from_numpy(detfill.uniform(tag + "/x", (1, 3, 256, 256))).float()
-        y = torch.from_numpy(detfill.uniform(tag + "/y", (1, 3, 256, 256))).float()
+        # second modality = one plane repeated to 3 channels, as MFNet feeds it (unetformer_mmsam.py:535)
+        y = torch.from_numpy(detfill.uniform(tag + "/y", (1, 1, 256, 256))).float().repeat(1, 3, 1, 1)
         with torch.no_grad():
             fx, fy = enc(x, y)
         save(tag, fx=fx, fy=fy)
@@ -155,6 +156,7 @@ def case_encoder():
 def _train_step_arrays(m, tag, B, ncls, ignore=None, size=256):
     import torch.nn.functional as F
     rgb, dsm, tgt = detfill.tiles(tag, B, size, ncls)
+    rgb, dsm = rgb.double(), dsm.double()        # model-level goldens are float64 (see case_model_tiny)
     if ignore is not None:
         tgt = tgt.clone(); tgt[:, :32, :48] = ignore
     m.train()
@@ -166,7 +168,7 @@ def _train_step_arrays(m, tag, B, ncls, ignore=None, size=256):
         out = m(rgb, dsm)
         flat = out.view(out.size(0), out.size(1), -1).transpose(1, 2).contiguous().view(-1, out.size(1))
         if ignore is None:
-            loss = F.cross_entropy(flat, tgt.view(-1), torch.ones(ncls))
+            loss = F.cross_entropy(flat, tgt.view(-1), torch.ones(ncls, dtype=torch.float64))
         else:
             loss = F.cross_entropy(flat, tgt.view(-1), ignore_index=ignore)
         loss.backward()
@@ -196,7 +198,9 @@ def case_model_tiny():
         tag = f"model_tiny_{mod}"
         m = _build_model(mod, "tiny")
         m.load_state_dict(detfill.fill_state_dict(m.state_dict(), tag + "/"))
+        m = m.double()      # fp32-representable weights, float64 arithmetic: pins the oracle to ~1e-10
         rgb, dsm, _ = detfill.tiles(tag, 2, 256, 6)
+        rgb, dsm = rgb.double(), dsm.double()
         m.eval()
         with torch.no_grad():
             out = m(rgb, dsm)
@@ -207,6 +211,7 @@ def case_model_tiny():
     tag = "model_tiny_ignore255"
     m = _build_model("sam_lora", "tiny", num_classes=2)
     m.load_state_dict(detfill.fill_state_dict(m.state_dict(), tag + "/"))
+    m = m.double()
     save(tag, **_train_step_arrays(m, tag, 2, 2, ignore=255))
 
 
@@ -217,7 +222,9 @@ def case_model_vitb():
         tag = f"model_vitb_{mod}"
         m = _build_model(mod, "vit_b")
         m.load_state_dict(detfill.fill_state_dict(m.state_dict(), tag + "/"))
+        m = m.double()
         rgb, dsm, _ = detfill.tiles(tag, 1, 256, 6)
+        rgb, dsm = rgb.double(), dsm.double()
         m.eval()
         sums = []
         hooks = [b.register_forward_hook(lambda mod_, i, o: sums.append(
