@@ -69,21 +69,31 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
   const int sch = lane & 7;          // destination chunk (16 B) inside the 128-B row
   const bf16_t* a_src[4];
   const bf16_t* w_src[4];
+  // K % 64 == 32: the last K-tile holds one 32-wide k-step. Lanes whose SOURCE chunk would lie in the
+  // missing half re-read the valid half instead (the LDS half they fill is never consumed), so no
+  // access leaves the operand rows.
+  const int nt = (p.K + BK - 1) / BK;
+  const bool half_tail = (p.K & (BK - 1)) != 0;
+  int a_tail[4], w_tail[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = wave * 32 + i * 8 + srow;
     int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
     int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
-    a_src[i] = p.A + (int64_t)gm * p.lda + ((sch ^ swz_x(row)) << 3);
-    w_src[i] = p.W + (int64_t)gn * p.ldw + ((sch ^ swz_w(row)) << 3);
+    const int ca = sch ^ swz_x(row), cw = sch ^ swz_w(row);
+    a_src[i] = p.A + (int64_t)gm * p.lda + (ca << 3);
+    w_src[i] = p.W + (int64_t)gn * p.ldw + (cw << 3);
+    a_tail[i] = (half_tail && ca >= 4) ? -32 : 0;
+    w_tail[i] = (half_tail && cw >= 4) ? -32 : 0;
   }
   auto stage = [&](int kt, int buf) {
     unsigned char* base = lds + buf * ((BM + BN) * BK * 2);
+    const bool last = kt == nt - 1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + kt * BK),
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + kt * BK + (last ? a_tail[i] : 0)),
                                        (lds_ptr_t)(base + (wave * 4 + i) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[i] + kt * BK),
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[i] + kt * BK + (last ? w_tail[i] : 0)),
                                        (lds_ptr_t)(base + BM * BK * 2 + (wave * 4 + i) * 1024), 16, 0, 0);
     }
   };
@@ -105,15 +115,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  const int nt = p.K / BK;
   stage(0, 0);
   for (int t = 0; t < nt; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
     const unsigned char* base = lds + (t & 1) * ((BM + BN) * BK * 2);
+    const int nks = (half_tail && t == nt - 1) ? 1 : 2;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      if (ks >= nks) break;
       bf16x8_t xf[4], wf[4];
       const int ch = fq + 4 * ks;
 #pragma unroll
@@ -242,7 +253,7 @@ extern "C" int mfnet_gemm_bf16(const void* A, int64_t lda, const void* W, int64_
                                void* out, int out_dtype, int64_t ldc, hipStream_t stream) {
   MF_CHECK_ARG(A && W && out, "gemm_bf16: null operand");
   MF_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm_bf16: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
-  MF_CHECK_ARG(K % BK == 0, "gemm_bf16: K=%lld must be a multiple of %d", (long long)K, BK);
+  MF_CHECK_ARG(K % 32 == 0, "gemm_bf16: K=%lld must be a multiple of 32", (long long)K);
   MF_CHECK_ARG(N % 16 == 0, "gemm_bf16: N=%lld must be a multiple of 16", (long long)N);
   MF_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K, "gemm_bf16: lda/ldw must be >= K and multiples of 8");
   MF_CHECK_ARG(ldc >= N && ldc % 8 == 0, "gemm_bf16: bad ldc");

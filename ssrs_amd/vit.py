@@ -32,28 +32,28 @@ BF = torch.bfloat16
 # frozen-weight caches (bf16 copies / transposes, resized tables); rebuilt when a parameter is
 # re-loaded (load_state_dict bumps _version) or moved (data_ptr changes)
 # ---------------------------------------------------------------------------------------------
-_cache = {}
-
-
 def _cached(key, params, build):
+    """Derived tensors live in a dict hung on the first source parameter (so they die with it and a
+    recycled id() can never alias another model's entry)."""
+    store = params[0].__dict__.setdefault("_mfnet_derived", {})
     sig = tuple((p.data_ptr(), p._version, p.device) for p in params)
-    hit = _cache.get(key)
+    hit = store.get(key)
     if hit is not None and hit[0] == sig:
         return hit[1]
     with torch.no_grad():
         val = build()
-    _cache[key] = (sig, val)
+    store[key] = (sig, val)
     return val
 
 
 def w_bf16(p: torch.Tensor, tag="") -> torch.Tensor:
     """bf16 copy of a frozen [N,K] weight."""
-    return _cached(("w", id(p), tag), (p,), lambda: ops.cast(p.detach().reshape(p.shape[0], -1).contiguous(), BF))
+    return _cached(("w", tag), (p,), lambda: ops.cast(p.detach().reshape(p.shape[0], -1).contiguous(), BF))
 
 
 def wT_bf16(p: torch.Tensor, tag="") -> torch.Tensor:
     """bf16 copy of the transpose [K,N] of a frozen [N,K] weight (operand of the dgrad GEMM)."""
-    return _cached(("wT", id(p), tag), (p,),
+    return _cached(("wT", tag), (p,),
                    lambda: ops.cast(p.detach().reshape(p.shape[0], -1).t().contiguous(), BF))
 
 
@@ -76,7 +76,7 @@ def build_rel_table(rel_h: torch.Tensor, rel_w: torch.Tensor, kh: int, kw: int):
 
 
 def _rel_tables(attn: nn.Module, kh: int, kw: int):
-    return _cached(("rel", id(attn), kh, kw), (attn.rel_h, attn.rel_w),
+    return _cached(("rel", kh, kw), (attn.rel_h, attn.rel_w),
                    lambda: build_rel_table(attn.rel_h, attn.rel_w, kh, kw))
 
 
@@ -255,11 +255,11 @@ class _Neck(torch.autograd.Function):
 
 
 def _neck3x3_w(w):     # [O, I, 3, 3] -> [O, 9*I] with k = tap*I + c  (im2col3x3 order)
-    return _cached(("n3", id(w)), (w,), lambda: ops.cast(w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous(), BF))
+    return _cached(("n3",), (w,), lambda: ops.cast(w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous(), BF))
 
 
 def _neck3x3_wT(w):
-    return _cached(("n3T", id(w)), (w,), lambda: ops.cast(w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).t().contiguous(), BF))
+    return _cached(("n3T",), (w,), lambda: ops.cast(w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).t().contiguous(), BF))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -511,7 +511,7 @@ class ImageEncoderViT(nn.Module):
         """abs-pos-embed bicubically resized to the token grid (image_encoder.py:126-135); frozen, so
         computed once per grid size and cached as a [T, D] fp32 matrix."""
         p = self.pos_embed
-        return _cached(("pos", id(p), Sh, Sw), (p,), lambda: F.interpolate(
+        return _cached(("pos", Sh, Sw), (p,), lambda: F.interpolate(
             p.detach().permute(0, 3, 1, 2), size=(Sh, Sw), mode="bicubic", align_corners=False
         ).permute(0, 2, 3, 1).reshape(Sh * Sw, -1).contiguous())
 

@@ -75,9 +75,16 @@ def test_tiny_encoder_matches_reference(mod):
     enc = _tiny_model(mod).image_encoder
     sd = detfill.fill_state_dict(enc.state_dict(), tag + "/")
     cfg = R.vit_cfg("tiny", mod=mod, dim=128, depth=2, heads=2, global_idx=(1,))
-    with torch.no_grad():
-        fx, fy = R.image_encoder(sd, "", _u(tag + "/x", (1, 3, 256, 256)), _u(tag + "/y", (1, 3, 256, 256)), cfg)
+    trainable = [k[2:] for k in g.files if k.startswith("g/")]
+    assert trainable and all(("lora_" in k) or ("Adapter" in k) for k in trainable)
+    for k in trainable:
+        sd[k].requires_grad_()
+    y = _u(tag + "/y", (1, 1, 256, 256)).repeat(1, 3, 1, 1)     # one plane x3, as MFNet feeds the DSM
+    fx, fy = R.image_encoder(sd, "", _u(tag + "/x", (1, 3, 256, 256)), y, cfg)
     assert rel_err(fx, g["fx"]) < TOL and rel_err(fy, g["fy"]) < TOL
+    ((fx * _u(tag + "/gx", fx.shape)).sum() + (fy * _u(tag + "/gy", fy.shape)).sum()).backward()
+    for k in trainable:
+        assert rel_err(sd[k].grad, g["g/" + k]) < (2e-4 if sd[k].numel() == 1 else 5e-5), k
 
 
 def _summ(t, n=256):

@@ -150,7 +150,17 @@ def case_encoder():
         y = torch.from_numpy(detfill.uniform(tag + "/y", (1, 1, 256, 256))).float().repeat(1, 3, 1, 1)
         with torch.no_grad():
             fx, fy = enc(x, y)
-        save(tag, fx=fx, fy=fy)
+        arrs = dict(fx=fx, fy=fy)
+        # backward with a FIXED upstream gradient on the two feature maps: PEFT gradients of the whole
+        # encoder (embed -> blocks -> neck) without the decoder's switching non-linearities in the way
+        gx = torch.from_numpy(detfill.uniform(tag + "/gx", tuple(fx.shape))).float()
+        gy = torch.from_numpy(detfill.uniform(tag + "/gy", tuple(fy.shape))).float()
+        ox, oy = enc(x, y)
+        ((ox * gx).sum() + (oy * gy).sum()).backward()
+        for n, p_ in enc.named_parameters():
+            if p_.grad is not None:
+                arrs["g/" + n] = p_.grad
+        save(tag, **arrs)
 
 
 def _train_step_arrays(m, tag, B, ncls, ignore=None, size=256):
