@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""MFNet hot-path benchmark: train tiles/s of ViT-B MMLoRA on synthetic 256x256 RGB+DSM tiles.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--mod sam_lora|sam_adpt] [--no-cpu]
+
+One "step" = one full training step (forward, cross-entropy, backward, SGD with momentum + weight
+decay) of `UNetFormer` (SAM ViT-B encoder, MMLoRA) over one batch of B=16 tiles per GPU that is
+already resident in HBM (BASELINE.json configs[1]). For N>1 the driver launches one rank per GPU
+with torch.distributed.run; the batch is sharded (weak scaling, B per GPU) and gradients are
+all-reduced over RCCL, overlapped with the encoder backward (ssrs_amd/trainer.py).
+
+Rank 0 prints ONE JSON line. Besides the contract fields it carries
+  roofline     - the dominant kernel (gemm_bf16_kernel, MFMA-bound): algorithmic FLOPs per launch
+                 (2*M*N*K averaged over the GEMM launches of one step) / its average launch duration,
+                 measured with HIP events on the launch stream in a second pass over the same steps;
+  cpu_baseline - the CPU restatement (oracle/, kind "port") timed on this box's host cores on
+                 BASELINE.json configs[0] (B=2 fwd+CE+bwd+SGD, a bounded sample).
+Nothing here reads /root/reference.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+TRAIN_GF_PER_TILE = {"sam_lora": 191.0, "sam_adpt": 211.0}     # SURVEY.md 8(d), tools/flops.py
+
+
+def build_model(mod, encoder, num_classes, device):
+    from ssrs_amd import detfill
+    from ssrs_amd.unetformer_mmsam import UNetFormer
+    args = argparse.Namespace(mod=mod, mid_dim=None, image_size=1024, multimask_output=1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = UNetFormer(num_classes=num_classes, encoder=encoder, args=args)
+    # random-init weights of the right architecture from the closed-form fill (no checkpoint offline)
+    m.load_state_dict(detfill.fill_state_dict(m.state_dict(), "bench/"))
+    return m.to(device).train()
+
+
+def cpu_baseline(mod, encoder, num_classes, budget_s=25.0):
+    """The oracle's train step (fp32, torch CPU ops, autograd) on configs[0]: B=2 tiles."""
+    from oracle import mfnet_ref as R
+    from ssrs_amd import detfill
+    from ssrs_amd.trainer import trainable_tensors
+    m = build_model(mod, encoder, num_classes, "cpu")
+    named, _ = trainable_tensors(m)
+    key = lambda n: n[4:] if n.startswith("sam.image_encoder.") else n      # noqa: E731
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    params = {key(n): sd[key(n)].clone().requires_grad_() for n, _ in named}
+    cfg = R.vit_cfg(encoder, mod=mod, num_classes=num_classes)
+    B = 2
+    rgb, dsm, tgt = detfill.tiles("bench/cpu", B, 256, num_classes)
+    bufs = {}
+    w = torch.ones(num_classes)
+    times = []
+    t_begin = time.time()
+    while True:
+        t0 = time.time()
+        work = dict(sd)
+        work.update(params)
+        st = R.BNState(True)
+        out = R.unetformer(work, rgb, dsm, cfg, training=True, bn_state=st)
+        loss = R.cross_entropy_2d(out, tgt, w)
+        grads = torch.autograd.grad(loss, list(params.values()))
+        with torch.no_grad():
+            R.sgd_step(params, dict(zip(params.keys(), grads)), bufs, 0.01, 0.9, 5e-4)
+        times.append(time.time() - t0)
+        if len(times) >= 2 and (time.time() - t_begin > budget_s or len(times) >= 12):
+            break
+    steady = times[1:]                         # first step pays allocator / thread-pool warm-up
+    med = sorted(steady)[len(steady) // 2]
+    return {"value": round(B / med, 3), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle fp32 train step, ViT-B {mod}, B={B} 256x256 tiles (BASELINE configs[0]); "
+                      f"median of {len(steady)} steps after 1 warm-up, {med:.3f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="tiles per GPU")
+    ap.add_argument("--mod", default="sam_lora")
+    ap.add_argument("--encoder", default="vit_b")
+    ap.add_argument("--classes", type=int, default=6)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with `python -m torch.distributed.run --nproc-per-node N ...`")
+        a.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a ROCm GPU: the MFNet hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from ssrs_amd import detfill, ops
+    from ssrs_amd.trainer import TrainEngine
+    model = build_model(a.mod, a.encoder, a.classes, dev)
+    eng = TrainEngine(model, lr=0.01, momentum=0.9, weight_decay=5e-4, class_weight=torch.ones(a.classes, device=dev))
+    rgb, dsm, tgt = detfill.tiles(f"bench/rank{rank}", a.batch, 256, a.classes)
+    rgb, dsm, tgt = rgb.to(dev), dsm.to(dev), tgt.to(dev)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        acc = eng.step(rgb, dsm, tgt)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        acc = eng.step(rgb, dsm, tgt)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    metrics = TrainEngine.read_metrics(acc)
+
+    roofline = None
+    if rank == 0 and not a.no_roofline:
+        # second pass over the same steps with an event pair around every GEMM launch
+        ops.GEMM_TRACE = []
+        for _ in range(a.steps):
+            eng.step(rgb, dsm, tgt)
+        torch.cuda.synchronize()
+        tr, ops.GEMM_TRACE = ops.GEMM_TRACE, None
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in tr)
+        fl = sum(f for _, _, f in tr)
+        achieved = fl / (ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(achieved, 2),
+                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
+                    "traffic": None, "launches_per_step": len(tr) // a.steps,
+                    "avg_launch_us": round(1e3 * ms / len(tr), 2), "gflop_per_launch": round(fl / len(tr) / 1e9, 3),
+                    "gemm_ms_per_step": round(ms / a.steps, 3)}
+    elif world > 1 and not a.no_roofline:
+        pass
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        tiles = world * a.batch * a.steps
+        out = {"metric": "train tiles/sec (256x256 RGB+DSM, ViT-B MMLoRA)" if a.mod == "sam_lora" else f"train tiles/sec (256x256 RGB+DSM, {a.encoder} {a.mod})",
+               "value": round(tiles / dt, 2), "unit": "tiles/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"{a.encoder} {a.mod} fine-tune step (fwd+CE+bwd+SGD), {a.batch} tiles of 256x256 RGB+DSM per GPU, "
+                                      f"{a.classes} classes, bf16 MFMA / fp32 accumulate+master (BASELINE configs[1])",
+                          "tiles_per_gpu": a.batch, "global_batch": world * a.batch, "parallelism": f"dp{world}"},
+               "loss": round(metrics["loss"], 5),
+               "algorithmic_train_tflops": round(world * a.batch * TRAIN_GF_PER_TILE.get(a.mod, 191.0) * 1e9 / (dt / a.steps) / 1e12, 2)}
+        if roofline is not None:
+            out["roofline"] = roofline
+        if world == 1 and not a.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(a.mod, a.encoder, a.classes)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,163 @@
+/* libmfnet_hip - C ABI of the MI355X (gfx950) kernels behind the MFNet hot path.
+ *
+ * The reference (AgPriyanshu/SSRS) has no FFI / plugin layer: its hot path is a chain of ATen ops
+ * inside torch.nn.Modules. Every entry point below therefore cites the reference
+ * Python code whose arithmetic it replaces (paths relative to the reference root), and
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C: device pointers (`void*`, `float*`), int64_t sizes / leading dimensions (in ELEMENTS),
+ *     `int` dtype enum, `hipStream_t` last. No torch types.
+ *   - return 0 on success, <0 on error (MFNET_ERR_*); the message is in mfnet_last_error()
+ *     (thread-local). Nothing throws across the boundary.
+ *   - all work is enqueued on `stream`; no entry point synchronises, allocates or frees device
+ *     memory, or keeps device state. Caller owns every buffer.
+ *   - "bf16" buffers hold raw bfloat16 bits; matrices are row-major; *_dtype is MFNET_F32 / MFNET_BF16.
+ *   - shapes that would make a kernel read or write out of bounds are rejected with MFNET_ERR_ARG
+ *     before anything is launched.
+ */
+#ifndef MFNET_HIP_H
+#define MFNET_HIP_H
+
+#include <stdint.h>
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFNET_OK 0
+#define MFNET_ERR_ARG (-1)
+#define MFNET_ERR_HIP (-2)
+#define MFNET_ERR_UNSUPPORTED (-3)
+
+#define MFNET_F32 0
+#define MFNET_BF16 1
+
+int mfnet_version(void);              /* 100 = 0.1.0 */
+const char* mfnet_last_error(void);   /* message of the last failing call on this thread */
+
+/* ---- LayerNorm over the last dim (eps 1e-6): nn.LayerNorm norm1/norm2 of the ViT blocks
+ * (medsam/models/ImageEncoder/vit/lora_block.py:67-68,83-84; adapter_fusionblock.py:78-79,101-103),
+ * LayerNorm2d of the neck (medsam/models/common/layer_norm.py:12-17) and Norm2d of fpn1x
+ * (unetformer_mmsam.py:14-22), all computed channels-last. x [rows, C] (ld = ldx) fp32|bf16 ->
+ * y fp32|bf16; mean/rstd [rows] fp32 optional (saved for backward). C % 4 == 0, C <= 2048. */
+int mfnet_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta,
+                        void* y, int y_dtype, int64_t ldy, float* mean, float* rstd, int64_t rows,
+                        int64_t C, float eps, hipStream_t stream);
+/* dx = LN'(dy) (+ dres: the residual-stream gradient, fused), written as fp32 (dx) and/or bf16
+ * (dx_bf16, ld = lddx); dgamma/dbeta [C] fp32 are ACCUMULATED into when non-null. */
+int mfnet_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, const void* x, int x_dtype, int64_t ldx,
+                        const float* mean, const float* rstd, const float* gamma, const float* dres,
+                        float* dx, void* dx_bf16, int64_t lddx, float* dgamma, float* dbeta, int64_t rows,
+                        int64_t C, hipStream_t stream);
+
+/* ---- bf16 MFMA GEMM with fused epilogues: every dense contraction of the encoder.
+ *   out[m,n] = act( sum_k A[m,k] W[n,k] + bias[n] + lr_scale * sum_j U[m,j] V[g(m)][n,j] ) + residual[m % res_row_mod, n]
+ * A [M,K] bf16 (lda), W [N,K] bf16 (ldw) - F.linear layout, fp32 accumulation. K % 32 == 0, N % 16 == 0.
+ * Low-rank term (fp32 U [M,R] (ldu), V [n_groups][N,R], g(m) = (m / rows_per_group) % n_groups, R in
+ * {4,8,12,16}): the LoRA update of lora.MergedLinear (medsam/models/common/loralib/layers.py:244-268,
+ * lr_scale = 1/r) and of lora.Linear incl. the cross-modal mix (layers.py:149-165), and their dgrads.
+ * act: 0 none | 1 exact GELU (out_pre, if non-null, receives the bf16 pre-activation) | 2 multiply by
+ * GELU'(aux[m,n]) (aux bf16: the saved pre-activation; MLP backward). With act 0, out_pre receives the
+ * value before the residual add. residual fp32 (ldres), may alias a fp32 `out`; res_row_mod > 0
+ * broadcasts a [res_row_mod, N] table over the rows (abs-pos-embed add, image_encoder.py:126-135).
+ * Replaces: qkv / proj (lora_block.py:169-196), MLPBlock (lora_block.py:104-108), Adapter fc1/fc2
+ * (common/adapter.py:16-25), PatchEmbed as im2col GEMM (image_encoder.py:189-197), neck convs (:104-120),
+ * and the transposed-weight dgrads of all of them. */
+int mfnet_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int64_t N, int64_t K,
+                    const float* bias, const float* U, int64_t ldu, const float* V, int64_t v_group_stride,
+                    int64_t rows_per_group, int n_groups, int R, float lr_scale, int act, const void* aux,
+                    int64_t ldaux, void* out_pre, int64_t ldpre, const float* residual, int64_t ldres,
+                    int64_t res_row_mod, void* out, int out_dtype, int64_t ldc, hipStream_t stream);
+
+/* ---- skinny products of the low-rank paths (layers.py:149-165,244-268 forward "x @ A^T" and the
+ * wgrads of lora_A / lora_B). nt: out[m,j] = scale * sum_k X[m,k] Wt[j,k], X bf16 [M,K], Wt fp32 [R,K],
+ * R <= 16. tn: out[c,j] (or out[j,c] if transposed) += scale * sum_m Y[m,c] U[m,j], Y bf16 [M,C], U fp32
+ * [M,R] (accumulates: zero `out` first). */
+int mfnet_skinny_nt(const void* X, int64_t ldx, const float* Wt, int64_t ldw, float* out, int64_t ldo,
+                    int64_t M, int64_t K, int R, float scale, hipStream_t stream);
+int mfnet_skinny_tn(const void* Y, int64_t ldy, const float* U, int64_t ldu, float* out, int64_t M, int64_t C,
+                    int R, int transposed, float scale, hipStream_t stream);
+
+/* ---- LoRA cross-modal mix (layers.py:159-160): a [M,r] fp32 = [x@Ax^T ; y@Ay^T] (RGB rows first) ->
+ * U [M,2r]: RGB rows [wx*ax, (1-wx)*ay], DSM rows [(1-wy)*ax, wy*ay]; backward returns da and ADDS
+ * (d lora_wx, d lora_wy) into dw[2]. wx/wy: device pointers to the trainable scalars. */
+int mfnet_lora_mix_fwd(const float* a, const float* wx, const float* wy, float* U, int64_t M, int r, hipStream_t stream);
+int mfnet_lora_mix_bwd(const float* P, const float* a, const float* wx, const float* wy, float* da, float* dw,
+                       int64_t M, int r, hipStream_t stream);
+
+/* ---- fused attention of the SAM blocks (lora_block.py:169-196 / adapter_fusionblock.py:176-198 with
+ * add_decomposed_rel_pos :281-317, window_partition / window_unpartition :199-245).
+ * qkv [G*Sh*Sw, 3*heads*hd] bf16 (q | k | v thirds, head-major), G = images x modalities, hd = 64.
+ * ws = 0: global attention over the Sh x Sw grid; ws > 0: ws x ws windows of the grid zero-padded at the
+ * bottom/right; only real queries are computed, padded keys/values are synthesised from qkv_bias (their
+ * input row is exactly zero after norm1), so nothing is inflated to the padded token count.
+ * tbl [NT,64] bf16 = [rel_h resized to Lh = 2*KH-1 rows ; rel_w resized to Lw = 2*KW-1 rows ; zero rows],
+ * NT % 32 == 0 (get_rel_pos' linear interpolation is done once on the host side, the tables are frozen);
+ * scores = scale * q.k + q.rel_h[qh-kh+KH-1] + q.rel_w[qw-kw+KW-1] with the UNSCALED q in the bias terms.
+ * Online softmax: no N x N tensor is materialised. out [G*Sh*Sw, heads*hd] bf16, lse [G,heads,Sh*Sw] fp32. */
+int mfnet_attn_fwd(const void* qkv, const float* qkv_bias, const void* tbl, void* out, float* lse, int64_t G,
+                   int64_t Sh, int64_t Sw, int64_t heads, int64_t hd, int64_t ws, int64_t Lh, int64_t Lw,
+                   int64_t NT, float scale, hipStream_t stream);
+/* dqkv [G*Sh*Sw, 3D] bf16 from dout; recomputes probabilities from lse. tblT [64,NT] bf16 = tbl^T.
+ * NT <= 96 (token grids up to 24 x 24) in this version: larger grids return MFNET_ERR_UNSUPPORTED. */
+int mfnet_attn_bwd(const void* qkv, const float* qkv_bias, const void* tbl, const void* tblT, const void* out,
+                   const void* dout, const float* lse, void* dqkv, int64_t G, int64_t Sh, int64_t Sw,
+                   int64_t heads, int64_t hd, int64_t ws, int64_t Lh, int64_t Lw, int64_t NT, float scale,
+                   hipStream_t stream);
+
+/* ---- data movement of the encoder. cast: fp32 <-> bf16, n % 8 == 0. im2col_patch: rgb [B,3,H,W] fp32 and
+ * dsm [B,H,W] fp32 (replicated to 3 channels, unetformer_mmsam.py:535) -> cols [2*B*(H/P)*(W/P), 3*P*P]
+ * bf16, RGB rows first, k in conv-weight order (image_encoder.py:189-197). im2col3x3 / col2im3x3: NHWC 3x3
+ * pad-1 unfold / fold for the neck conv and its dgrad (image_encoder.py:112-118). transpose_bf16:
+ * x [M,N] -> y [N,Mp] zero-padded (operand prep for adapter wgrads). */
+int mfnet_cast(const void* x, int x_dtype, void* y, int y_dtype, int64_t n, hipStream_t stream);
+int mfnet_im2col_patch(const float* rgb, const float* dsm, void* cols, int64_t B, int64_t H, int64_t W, int64_t P,
+                       hipStream_t stream);
+int mfnet_im2col3x3(const void* x, void* cols, int64_t G, int64_t H, int64_t W, int64_t C, hipStream_t stream);
+int mfnet_col2im3x3(const void* dcols, float* dx, int64_t G, int64_t H, int64_t W, int64_t C, hipStream_t stream);
+int mfnet_transpose_bf16(const void* x, int64_t ld, void* y, int64_t M, int64_t N, int64_t Mp, hipStream_t stream);
+
+/* ---- MMAdapter glue (adapter_fusionblock.py:104-108): out = h + w*ada_own + (1-w)*ada_other per modality
+ * (rows [0,M/2) RGB, [M/2,M) DSM); backward gives d ada (bf16) and ADDS (d wx_Adapter, d wy_Adapter) into
+ * dw[2]. gelu_fwd/bwd: exact GELU; add_bf16: elementwise sum; bias_grad: out[n] += sum_m dy[m,n]. */
+int mfnet_adapter_mix(const float* h, const float* ada, const float* wx, const float* wy, float* out, void* reserved,
+                      int64_t M, int64_t D, hipStream_t stream);
+int mfnet_adapter_mix_bwd(const float* dh, const float* ada, const float* wx, const float* wy, void* dada, float* dw,
+                          void* reserved, int64_t M, int64_t D, hipStream_t stream);
+int mfnet_gelu_fwd(const float* x, float* y, int64_t n, hipStream_t stream);
+int mfnet_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, hipStream_t stream);
+int mfnet_add_bf16(const void* a, const void* b, void* out, int64_t n, hipStream_t stream);
+int mfnet_bias_grad(const void* dy, int64_t ld, float* out, int64_t M, int64_t N, hipStream_t stream);
+
+/* ---- loss / optimiser. CrossEntropy2d (utils2.py:115-127; ignore_index variant
+ * train_multiscale_main.py:30-43) on NCHW fp32 logits without the transpose copy. fwd ADDS into acc[4] =
+ * {sum w[t]*nll, sum w[t], #(argmax == t), #valid} (zero it first; loss = acc[0]/acc[1]) and optionally writes
+ * the arg-max class per pixel (uint8). bwd: dlogits = gscale * w[t] * (softmax - onehot) / acc[1].
+ * sgd_flat: torch.optim.SGD of trainer.py:111-116 over one flat buffer: d = gscale*g + wd*p;
+ * buf = momentum*buf + d; p -= lr*buf (buf zero-initialised; gscale = 1/world folds the DP average). */
+int mfnet_ce_loss_fwd(const float* logits, const int64_t* target, const float* weight, float* acc,
+                      unsigned char* pred, int64_t B, int64_t C, int64_t HW, int64_t ignore_index, hipStream_t stream);
+int mfnet_ce_loss_bwd(const float* logits, const int64_t* target, const float* weight, const float* acc,
+                      float* dlogits, float gscale, int64_t B, int64_t C, int64_t HW, int64_t ignore_index,
+                      hipStream_t stream);
+int mfnet_sgd_flat(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float wd,
+                   float gscale, hipStream_t stream);
+
+/* ---- sliding-window inference (evaluator.py:113-176, inference.py:535-568). tile_accumulate:
+ * pred [C,H,W] fp32 += logits [n,C,h,w] at (row, col) = coords[n][2] int32 - the reference's
+ * `pred[x:x+w, y:y+h] += out` overlap merge, on the device (atomic != 0 allows overlapping tiles within one
+ * call). argmax_chw: uint8 class map (first maximum wins, like np.argmax). minmax + scale_shift: DSM
+ * min-max normalisation (mode 0 evaluator.py:100-111 whole raster; mode 1 inference.py:547-555 per tile,
+ * zero when max == min). */
+int mfnet_tile_accumulate(float* pred, const float* logits, const int* coords, int64_t n, int64_t C, int64_t H,
+                          int64_t W, int64_t h, int64_t w, int atomic, hipStream_t stream);
+int mfnet_argmax_chw(const float* pred, unsigned char* out, int64_t C, int64_t N, hipStream_t stream);
+int mfnet_minmax(const float* x, float* out, int64_t n, hipStream_t stream);
+int mfnet_scale_shift(const float* x, float* y, const float* mm, float unused, int64_t n, int mode, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFNET_HIP_H */

@@ -40,7 +40,7 @@ _SIGS = {
     "mfnet_attn_bwd": [P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, F, P],
     "mfnet_ce_loss_fwd": [P, P, P, P, P, I64, I64, I64, I64, P],
     "mfnet_ce_loss_bwd": [P, P, P, P, P, F, I64, I64, I64, I64, P],
-    "mfnet_sgd_flat": [P, P, P, I64, F, F, F, P],
+    "mfnet_sgd_flat": [P, P, P, I64, F, F, F, F, P],
     "mfnet_tile_accumulate": [P, P, P, I64, I64, I64, I64, I64, I64, I, P],
     "mfnet_argmax_chw": [P, P, I64, I64, P],
     "mfnet_minmax": [P, P, I64, P],

@@ -16,12 +16,13 @@ static inline unsigned grid_for(int64_t work_items, int64_t cap = 8192) {
 
 // ----------------------------------------------------------------------------------- cross entropy
 #define CE_MAXC 32
-// acc[0] += sum w[t]*nll ; acc[1] += sum w[t]   (pixels with t == ignore contribute nothing)
+// acc[0] += sum w[t]*nll ; acc[1] += sum w[t] ; acc[2] += #(argmax == t) ; acc[3] += #valid pixels
+// (pixels with t == ignore contribute nothing)
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
                                                      const float* __restrict__ weight, float* __restrict__ acc,
                                                      unsigned char* __restrict__ pred, int64_t B, int C, int64_t HW,
                                                      int64_t ignore) {
-  float ls = 0.f, ws = 0.f;
+  float ls = 0.f, ws = 0.f, nc = 0.f, nv = 0.f;
   const int64_t total = B * HW;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t b = i / HW, px = i - b * HW;
@@ -40,17 +41,18 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     const float w = weight ? weight[t] : 1.f;
     ls += w * (mx + __logf(se) - lp[t * HW]);
     ws += w;
+    nc += (am == (int)t) ? 1.f : 0.f;
+    nv += 1.f;
   }
   ls = wave_sum(ls);
   ws = wave_sum(ws);
-  __shared__ float sh[8];
+  nc = wave_sum(nc);
+  nv = wave_sum(nv);
+  __shared__ float sh[16];
   const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { sh[wave] = ls; sh[4 + wave] = ws; }
+  if ((threadIdx.x & 63) == 0) { sh[wave] = ls; sh[4 + wave] = ws; sh[8 + wave] = nc; sh[12 + wave] = nv; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    atomicAdd(acc, sh[0] + sh[1] + sh[2] + sh[3]);
-    atomicAdd(acc + 1, sh[4] + sh[5] + sh[6] + sh[7]);
-  }
+  if (threadIdx.x < 4) atomicAdd(acc + threadIdx.x, sh[4 * threadIdx.x] + sh[4 * threadIdx.x + 1] + sh[4 * threadIdx.x + 2] + sh[4 * threadIdx.x + 3]);
 }
 // dlogits = gscale * w[t] * (softmax - onehot) / acc[1]
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
@@ -98,21 +100,24 @@ extern "C" int mfnet_ce_loss_bwd(const float* logits, const int64_t* target, con
 }
 
 // ----------------------------------------------------------------------------------- SGD
-// d = g + wd*p ; buf = mom*buf + d ; p -= lr*buf   (buf zero-initialised => first step buf = d)
+// d = gscale*g + wd*p ; buf = mom*buf + d ; p -= lr*buf   (buf zero-initialised => first step buf = d).
+// gscale = 1/world folds the data-parallel gradient average into the update.
 __global__ __launch_bounds__(256) void sgd_flat_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                       float* __restrict__ buf, int64_t n, float lr, float mom, float wd) {
+                                                       float* __restrict__ buf, int64_t n, float lr, float mom, float wd,
+                                                       float gscale) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float pv = p[i];
-    float d = g[i] + wd * pv;
+    float d = gscale * g[i] + wd * pv;
     if (buf) { d = mom * buf[i] + d; buf[i] = d; }
     p[i] = pv - lr * d;
   }
 }
-extern "C" int mfnet_sgd_flat(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float wd, hipStream_t stream) {
+extern "C" int mfnet_sgd_flat(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float wd,
+                              float gscale, hipStream_t stream) {
   MF_CHECK_ARG(p && g && n >= 0, "sgd_flat: bad args");
   MF_CHECK_ARG(momentum == 0.f || buf, "sgd_flat: momentum needs a buffer");
   if (n == 0) return MFNET_OK;
-  hipLaunchKernelGGL(sgd_flat_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, momentum != 0.f ? buf : nullptr, n, lr, momentum, wd);
+  hipLaunchKernelGGL(sgd_flat_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, momentum != 0.f ? buf : nullptr, n, lr, momentum, wd, gscale);
   MF_LAUNCH_CHECK("sgd_flat");
   return MFNET_OK;
 }

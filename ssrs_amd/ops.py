@@ -15,6 +15,10 @@ from ._lib import BF16, F32, MfnetError, call
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
+# bench.py sets this to a list to time every GEMM launch with a pair of events recorded on the stream
+# the kernel is launched on: entries are (start_event, end_event, algorithmic_flops).
+GEMM_TRACE = None
+
 
 def _stream(t: torch.Tensor):
     return torch.cuda.current_stream(t.device).cuda_stream
@@ -91,11 +95,17 @@ def gemm(a, w, *, bias=None, U=None, V=None, rows_per_group=0, n_groups=1, lr_sc
         R = U.shape[-1]
         assert V.shape[-1] == R and V.shape[-2] == N
         vgs = V.stride(0) if V.dim() == 3 else 0
+    if GEMM_TRACE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(a.device))
     call("mfnet_gemm_bf16", a2.data_ptr(), lda, w.data_ptr(), w.stride(0), M, N, K, _p(bias),
          _p(U), R if U is not None else 0, _p(V), vgs, rows_per_group, n_groups, R, float(lr_scale), act,
          _p(aux), aux.stride(-2) if aux is not None else 0, _p(pre), N if pre is not None else 0,
          _p(residual), residual.stride(-2) if residual is not None else 0, res_row_mod,
          out.data_ptr(), _DT[out.dtype], out.stride(-2), _stream(a))
+    if GEMM_TRACE is not None:
+        ev1.record(torch.cuda.current_stream(a.device))
+        GEMM_TRACE.append((ev0, ev1, 2.0 * M * N * K))
     return (out, pre) if want_pre else out
 
 
@@ -211,7 +221,7 @@ def ce_loss_fwd(logits, target, weight=None, ignore_index=-100, want_pred=False)
     assert logits.is_contiguous() and logits.dtype == torch.float32 and target.dtype == torch.int64 and target.is_contiguous()
     B, C = logits.shape[:2]
     HW = logits.numel() // (B * C)
-    acc = torch.zeros(2, dtype=torch.float32, device=logits.device)
+    acc = torch.zeros(4, dtype=torch.float32, device=logits.device)   # sum w*nll, sum w, #correct, #valid
     pred = torch.empty((B,) + tuple(logits.shape[2:]), dtype=torch.uint8, device=logits.device) if want_pred else None
     call("mfnet_ce_loss_fwd", logits.data_ptr(), target.data_ptr(), _p(weight), acc.data_ptr(), _p(pred),
          B, C, HW, ignore_index, _stream(logits))
@@ -227,10 +237,11 @@ def ce_loss_bwd(logits, target, acc, weight=None, ignore_index=-100, gscale=1.0)
     return d
 
 
-def sgd_flat(p, g, buf, lr, momentum, wd):
+def sgd_flat(p, g, buf, lr, momentum, wd, gscale=1.0):
     _chk(p, g, buf)
     assert p.is_contiguous() and g.is_contiguous() and p.numel() == g.numel()
-    call("mfnet_sgd_flat", p.data_ptr(), g.data_ptr(), _p(buf), p.numel(), float(lr), float(momentum), float(wd), _stream(p))
+    call("mfnet_sgd_flat", p.data_ptr(), g.data_ptr(), _p(buf), p.numel(), float(lr), float(momentum), float(wd),
+         float(gscale), _stream(p))
 
 
 def tile_accumulate(pred, logits, coords, atomic=True):

@@ -1,0 +1,393 @@
+"""Training side of the MFNet hot path: the train step of the reference's `Trainer.train_epoch`
+(trainer.py:146-197; ignore-255 / skip-empty variant train_multiscale_main.py:113-171) as an
+MI355X-native engine, plus drop-ins for `ModelWrapper` (model_wrapper.py:10-137) and `Trainer`
+(trainer.py:26-465) that keep the reference's constructor / method surface.
+
+What changes relative to the reference loop (the arithmetic of one step does not):
+  * every tensor that receives a gradient lives in ONE flat fp32 parameter buffer with a matching flat
+    gradient buffer and momentum buffer: `zero_grad` is one memset, `SGD.step` one fused kernel
+    (mfnet_sgd_flat) instead of 333 (MMLoRA) / 357 (MMAdapter) small ones;
+  * cross-entropy runs on the NCHW logits directly (mfnet_ce_loss_fwd/bwd: no transpose copy,
+    utils2.py:115-127), and also yields the arg-max accuracy of the WHOLE batch on the device, so the
+    reference's per-step `loss.item()` x3 + full-logit D2H (trainer.py:163-175) becomes one 16-byte read
+    every `sync_every` steps;
+  * data parallel: one process per GPU, the flat gradient buffer is cut into two buckets in backward
+    order (decoder+FPN+fusion first, encoder PEFT second); each bucket is all-reduced (RCCL, SUM) as
+    soon as its last gradient has been accumulated, overlapping the remaining encoder backward, and the
+    1/world average is folded into the SGD kernel. SAM's prompt encoder / mask decoder never receive a
+    gradient and are not part of any bucket. BatchNorm uses per-replica statistics.
+"""
+from __future__ import annotations
+
+import math
+import time
+from dataclasses import dataclass, field
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import ops
+
+_ALIGN = 64          # elements: every tensor starts on a 256-byte boundary inside the flat buffers
+
+
+# --------------------------------------------------------------------------------------------------
+# loss (drop-in for utils2.CrossEntropy2d and the ignore_index variant)
+# --------------------------------------------------------------------------------------------------
+class _CE2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, weight, ignore_index):
+        logits = logits.contiguous()
+        acc, _ = ops.ce_loss_fwd(logits, target.contiguous(), weight, ignore_index)
+        ctx.save_for_backward(logits, target, acc)
+        ctx.weight, ctx.ignore = weight, ignore_index
+        return acc[0] / acc[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, acc = ctx.saved_tensors
+        d = ops.ce_loss_bwd(logits, target.contiguous(), acc, ctx.weight, ctx.ignore, 1.0)
+        return d * g, None, None, None
+
+
+def CrossEntropy2d(input, target, weight=None, size_average=True, ignore_index=-100):
+    """utils2.py:115-127 (mean over pixels; `weight` = per-class weights) and, with ignore_index=255,
+    train_multiscale_main.py:30-43. input (B,C,H,W) fp32 logits, target (B,H,W) int64."""
+    if input.dim() != 4:
+        raise ValueError("Expected 4 dimensions (got {})".format(input.dim()))
+    if not size_average:
+        raise NotImplementedError("size_average=False is never used by MFNet")
+    return _CE2d.apply(input.float(), target, weight, int(ignore_index))
+
+
+# --------------------------------------------------------------------------------------------------
+# engine
+# --------------------------------------------------------------------------------------------------
+def trainable_tensors(model: nn.Module) -> List[Tuple[str, nn.Parameter]]:
+    """Parameters that receive a gradient in MFNet's step, in bucket order: everything outside the
+    encoder first (its backward runs first), encoder PEFT tensors second. `sam.prompt_encoder` /
+    `sam.mask_decoder` are requires_grad but unreachable (unetformer_mmsam.py:533-563)."""
+    head, enc = [], []
+    for n, p in model.named_parameters():
+        if not p.requires_grad or n.startswith(("sam.prompt_encoder.", "sam.mask_decoder.")):
+            continue
+        (enc if ".image_encoder." in "." + n else head).append((n, p))
+    return head + enc, len(head)
+
+
+class TrainEngine:
+    """One MFNet training step on one GPU (optionally one rank of a data-parallel group)."""
+
+    def __init__(self, model: nn.Module, lr: float = 0.01, momentum: float = 0.9, weight_decay: float = 5e-4,
+                 milestones: Sequence[int] = (25, 35, 45), gamma: float = 0.1, class_weight: Optional[torch.Tensor] = None,
+                 ignore_index: int = -100, process_group=None, overlap: bool = True):
+        self.model = model
+        self.base_lr, self.momentum, self.weight_decay = float(lr), float(momentum), float(weight_decay)
+        self.milestones, self.gamma = sorted(int(m) for m in milestones), float(gamma)
+        self.epoch = 0
+        self.ignore_index = int(ignore_index)
+        self.class_weight = class_weight
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
+        self.overlap = overlap
+        named, n_head = trainable_tensors(model)
+        if not named:
+            raise ValueError("model has no trainable tensors")
+        self.names = [n for n, _ in named]
+        self.params = [p for _, p in named]
+        dev = self.params[0].device
+        offs, off = [], 0
+        for p in self.params:
+            offs.append(off)
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.offsets, self.total = offs, off
+        split = offs[n_head] if n_head < len(offs) else off
+        self.bucket_bounds = [(0, split), (split, off)] if 0 < split < off else [(0, off)]
+        self.bucket_of = [0 if (i < n_head or len(self.bucket_bounds) == 1) else 1 for i in range(len(self.params))]
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(off, dtype=torch.float32, device=dev) if momentum else None
+        with torch.no_grad():
+            for p, o in zip(self.params, offs):
+                if p.dtype != torch.float32:
+                    raise TypeError("MFNet trains fp32 master parameters")
+                v = self.flat_p[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+        self._pending = [0] * len(self.bucket_bounds)
+        self._works = []
+        self._bucket_size = [self.bucket_of.count(b) for b in range(len(self.bucket_bounds))]
+        self._hooks = []
+        if self.world > 1:
+            for i, p in enumerate(self.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(self.bucket_of[i])))
+        self.steps = 0
+
+    # ---- schedule (optim.lr_scheduler.MultiStepLR, trainer.py:118-122)
+    @property
+    def lr(self) -> float:
+        return self.base_lr * self.gamma ** sum(1 for m in self.milestones if m <= self.epoch)
+
+    def scheduler_step(self):
+        self.epoch += 1
+
+    # ---- data-parallel gradient exchange
+    def _make_hook(self, b):
+        def hook(_p):
+            self._pending[b] += 1
+            if self._pending[b] == self._bucket_size[b] and self.overlap:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        lo, hi = self.bucket_bounds[b]
+        self._works.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _finish_exchange(self):
+        if self.world == 1:
+            return
+        if not self.overlap or any(c != s for c, s in zip(self._pending, self._bucket_size)):
+            # a bucket whose hooks did not all fire (a tensor without gradient this step) is reduced whole
+            done = len(self._works)
+            for b in range(done, len(self.bucket_bounds)):
+                self._launch(b)
+        for w in self._works:
+            w.wait()                      # stream-level wait: the compute stream waits for RCCL, the host does not
+        self._works.clear()
+        self._pending = [0] * len(self.bucket_bounds)
+
+    # ---- one step
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def forward_backward(self, rgb, dsm, target, want_pred=False):
+        """-> (acc [4] device tensor: sum w*nll, sum w, #correct, #valid ; pred uint8 | None)."""
+        out = self.model(rgb, dsm, mode="Train")
+        out = out.contiguous()
+        acc, pred = ops.ce_loss_fwd(out, target, self.class_weight, self.ignore_index, want_pred=want_pred)
+        d = ops.ce_loss_bwd(out, target, acc, self.class_weight, self.ignore_index, 1.0)
+        out.backward(d)
+        return acc, pred
+
+    def optimizer_step(self):
+        self._finish_exchange()
+        ops.sgd_flat(self.flat_p, self.flat_g, self.flat_m, self.lr, self.momentum, self.weight_decay, 1.0 / self.world)
+
+    def step(self, rgb: torch.Tensor, dsm: torch.Tensor, target: torch.Tensor):
+        """zero_grad -> forward -> CE -> backward (-> all-reduce) -> SGD. Returns the device tensor
+        [sum w*nll, sum w, #correct, #valid] of THIS rank's batch; nothing is synchronised."""
+        self.zero_grad()
+        acc, _ = self.forward_backward(rgb, dsm, target)
+        self.optimizer_step()
+        self.steps += 1
+        return acc
+
+    @staticmethod
+    def read_metrics(acc: torch.Tensor) -> Dict[str, float]:
+        a = acc.tolist()                  # the only host sync
+        return {"loss": a[0] / a[1] if a[1] else float("nan"), "accuracy": 100.0 * a[2] / a[3] if a[3] else float("nan")}
+
+    def state_dict(self):
+        """optimizer state for a true resume (the reference saves weights only, trainer.py:379-394)."""
+        return {"momentum": None if self.flat_m is None else self.flat_m.clone(), "epoch": self.epoch, "steps": self.steps,
+                "names": list(self.names)}
+
+    def load_state_dict(self, sd):
+        if sd.get("names") != self.names:
+            raise ValueError("optimizer state belongs to a different parameter layout")
+        if self.flat_m is not None and sd["momentum"] is not None:
+            self.flat_m.copy_(sd["momentum"])
+        self.epoch, self.steps = int(sd["epoch"]), int(sd["steps"])
+
+
+# --------------------------------------------------------------------------------------------------
+# reference API mirrors
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class TrainingConfig:
+    """config.py:25-40."""
+    base_lr: float = 0.01
+    momentum: float = 0.9
+    weight_decay: float = 0.0005
+    scheduler_milestones: List[int] = None
+    scheduler_gamma: float = 0.1
+    batch_size: int = 10
+    window_size: Tuple[int, int] = (256, 256)
+    n_classes: int = 6
+    cache: bool = True
+
+    def __post_init__(self):
+        if self.scheduler_milestones is None:
+            self.scheduler_milestones = [25, 35, 45]
+
+
+class ModelWrapper:
+    """model_wrapper.py:10-137: builds `UNetFormer(num_classes).cuda()`, counts parameters by the
+    'lora_' name test, saves / loads plain state dicts. Extra keyword arguments go to UNetFormer."""
+
+    def __init__(self, num_classes: int = 6, **model_kwargs):
+        from .unetformer_mmsam import UNetFormer
+        self.num_classes = num_classes
+        self.model = UNetFormer(num_classes=num_classes, **model_kwargs).cuda()
+
+    def get_parameter_counts(self) -> Dict[str, int]:
+        total = sum(p.nelement() for _, p in self.model.named_parameters())
+        enc = lora = 0
+        for n, p in self.model.image_encoder.named_parameters():
+            if "lora_" not in n:
+                enc += p.nelement()
+            else:
+                lora += p.nelement()
+        return {"total": total, "image_encoder": enc, "lora": lora, "others": total - enc - lora}
+
+    def print_parameter_summary(self) -> None:
+        c = self.get_parameter_counts()
+        print("=" * 50 + "\nMODEL PARAMETER SUMMARY\n" + "=" * 50)
+        print(f"Total Parameters:     {c['total']:,}\nImage Encoder:        {c['image_encoder']:,}")
+        print(f"LoRA Parameters:      {c['lora']:,}\nOther Parameters:     {c['others']:,}\n" + "=" * 50)
+
+    def get_model(self) -> nn.Module:
+        return self.model
+
+    def load_weights(self, checkpoint_path: str, strict: bool = False) -> None:
+        sd = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+        if isinstance(sd, dict):                      # inference.py:161-166 accepts wrapped formats too
+            sd = sd.get("model_state_dict", sd.get("state_dict", sd))
+        self.model.load_state_dict(sd, strict=strict)
+        print(f"Successfully loaded weights from: {checkpoint_path}")
+
+    def save_weights(self, save_path: str) -> None:
+        torch.save(self.model.state_dict(), save_path)
+        print(f"Model weights saved to: {save_path}")
+
+    def set_train_mode(self) -> None:
+        self.model.train()
+
+    def set_eval_mode(self) -> None:
+        self.model.eval()
+
+    def forward(self, image_patches, dsm_patches, mode: str = "Train"):
+        return self.model(image_patches, dsm_patches, mode=mode)
+
+
+class Trainer:
+    """trainer.py:26-465 with the data loader injected (dataset I/O is host code outside the hot path).
+
+    `Trainer(model_wrapper, evaluator=None, train_loader=..., training=TrainingConfig(), epochs=50,
+    save_epoch=1, ignore_index=-100, skip_empty=False)`; `.train_epoch(epoch) -> {'avg_loss',
+    'training_time'}`, `.validate(epoch)`, `.save_checkpoint(epoch, miou)`, `.train(epochs, save_epoch)`.
+    `skip_empty=True` reproduces MultiscaleTrainer's "skip batches without a building pixel" rule
+    (train_multiscale_main.py:113-125), which costs one host sync per batch as in the reference.
+    Under torch.distributed every rank runs the same loop on its shard of the batches; metrics are
+    all-reduced when they are read, and only rank 0 prints / saves."""
+
+    def __init__(self, model_wrapper: ModelWrapper, evaluator=None, *, train_loader: Iterable = None,
+                 training: Optional[TrainingConfig] = None, epochs: int = 50, save_epoch: int = 1,
+                 ignore_index: int = -100, skip_empty: bool = False, output_dir: str = "./results/",
+                 model_name: str = "UNetformer", sync_every: int = 10, validate_fn=None):
+        self.model_wrapper = model_wrapper
+        self.model = model_wrapper.get_model()
+        self.evaluator = evaluator
+        self.training = training or TrainingConfig()
+        self.train_loader = train_loader
+        self.epochs, self.save_epoch = epochs, save_epoch
+        self.best_miou = 0.82                                      # trainer.py:42
+        self.skip_empty = skip_empty
+        self.output_dir, self.model_name = output_dir, model_name
+        self.sync_every = max(1, int(sync_every))
+        self.validate_fn = validate_fn
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        dev = next(self.model.parameters()).device
+        t = self.training
+        # WEIGHTS = ones(N_CLASSES) (utils2.py:13); the ignore-255 variant uses no weights
+        w = torch.ones(t.n_classes, device=dev) if ignore_index == -100 else None
+        self.engine = TrainEngine(self.model, lr=t.base_lr, momentum=t.momentum, weight_decay=t.weight_decay,
+                                  milestones=t.scheduler_milestones, gamma=t.scheduler_gamma, class_weight=w,
+                                  ignore_index=ignore_index)
+        self.losses: List[float] = []
+        self.recent_losses: List[float] = []
+        self.recent_accuracies: List[float] = []
+        self.loss_trend_window = 20
+
+    def _reduce(self, acc):
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            acc = acc.clone()
+            dist.all_reduce(acc)
+        return acc
+
+    def train_epoch(self, epoch: int) -> Dict[str, float]:
+        self.model.train()
+        start = time.time()
+        dev = self.engine.flat_p.device
+        pend = torch.zeros(4, device=dev)
+        epoch_acc = torch.zeros(4, device=dev)
+        nb = 0
+        for batch_idx, (data, dsm, target) in enumerate(self.train_loader):
+            data = data.to(dev, non_blocking=True)
+            dsm = dsm.to(dev, non_blocking=True)
+            target = target.to(dev, non_blocking=True)
+            if self.skip_empty:
+                valid = target[target != 255]
+                if valid.numel() == 0 or bool(torch.all(valid == 0)):
+                    continue
+            acc = self.engine.step(data, dsm, target)
+            pend += acc
+            epoch_acc += acc
+            nb += 1
+            if nb % self.sync_every == 0:
+                m = TrainEngine.read_metrics(self._reduce(pend))
+                pend.zero_()
+                self.losses.append(m["loss"])
+                self.recent_losses = (self.recent_losses + [m["loss"]])[-self.loss_trend_window:]
+                self.recent_accuracies = (self.recent_accuracies + [m["accuracy"]])[-self.loss_trend_window:]
+                if self.rank == 0:
+                    print(f"\rEpoch {epoch:2d}/{self.epochs} {batch_idx:4d} | Loss: {m['loss']:7.4f} | "
+                          f"Acc: {m['accuracy']:5.1f}% | LR: {self.engine.lr:.2e}", end="")
+                self._check_early_overfitting_signs()
+        m = TrainEngine.read_metrics(self._reduce(epoch_acc)) if nb else {"loss": float("nan")}
+        if self.rank == 0:
+            print()
+        return {"avg_loss": m["loss"], "training_time": time.time() - start}
+
+    def _check_early_overfitting_signs(self):
+        """trainer.py:295-319: stop when the recent mean batch accuracy exceeds 99 % (rank-consistent:
+        the accuracies it looks at are already all-reduced)."""
+        if len(self.recent_accuracies) >= 5 and sum(self.recent_accuracies[-5:]) / 5 > 99.0:
+            raise KeyboardInterrupt("auto-stop: recent training accuracy above 99 %")
+
+    def validate(self, epoch: int) -> float:
+        if self.validate_fn is None and self.evaluator is None:
+            print("No evaluator provided, skipping validation")
+            return 0.0
+        self.model.eval()
+        try:
+            miou = self.validate_fn(self.model_wrapper) if self.validate_fn else self.evaluator.evaluate(self.model_wrapper)
+        finally:
+            self.model.train()
+        return float(miou)
+
+    def save_checkpoint(self, epoch: int, miou: float) -> None:
+        if miou > self.best_miou:
+            self.best_miou = miou
+            if self.rank == 0:
+                import os
+                os.makedirs(self.output_dir, exist_ok=True)
+                self.model_wrapper.save_weights(f"{self.output_dir}{self.model_name}_epoch{epoch}_{miou:.4f}")
+        elif self.rank == 0:
+            print(f"   No improvement (best: {self.best_miou:.4f})")
+
+    def train(self, epochs: Optional[int] = None, save_epoch: Optional[int] = None) -> None:
+        epochs = self.epochs if epochs is None else epochs
+        save_epoch = self.save_epoch if save_epoch is None else save_epoch
+        for epoch in range(1, epochs + 1):
+            t0 = time.time()
+            metrics = self.train_epoch(epoch)
+            self.engine.scheduler_step()
+            if self.rank == 0:
+                print(f"EPOCH {epoch:2d}/{epochs}  train {metrics['training_time']:.2f}s  total {time.time() - t0:.2f}s  "
+                      f"avg loss {metrics['avg_loss']:.4f}  lr {self.engine.lr:.2e}")
+            if epoch % save_epoch == 0:
+                self.save_checkpoint(epoch, self.validate(epoch))
