@@ -8,6 +8,11 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
+# torch must be loaded FIRST: it ships its own libamdhip64.so.7 and owns the device memory and streams
+# this library works on. Loading libmfnet_hip.so before torch would bind the process to the system HIP
+# runtime instead and torch's allocations would belong to another runtime ("no ROCm-capable device").
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmfnet_hip.so")
 

@@ -62,11 +62,15 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(const bf16_t* __restrict
 }
 
 // grid: (col strips of 512, row splits); block = 4 waves sharing the strip, each wave a row slice.
+// The four waves' partial sums are combined in LDS and only wave 0 issues the global float adds, and
+// the row splits are sized for ~256 workgroups: the output has only C*R addresses, so every extra split
+// is one more atomic per address (the first version had 4 per split and ~700 per address).
 template <int R>
 __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* __restrict__ Y, int64_t ldy,
                                                         const float* __restrict__ U, int64_t ldu,
                                                         float* __restrict__ out, int64_t M, int C,
                                                         int64_t rows_per_block, int transposed, float scale) {
+  __shared__ float red[64][8 * R + 1];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int c0 = (blockIdx.x * 64 + lane) * 8;
@@ -80,6 +84,7 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int j = 0; j < R; ++j) acc[e][j] = 0.f;
   if (active) {
+#pragma unroll 4
     for (int64_t m = r_begin + wave; m < r_end; m += 4) {
       const u32x4_t yv = *reinterpret_cast<const u32x4_t*>(Y + m * ldy + c0);
       const float y[8] = {bf16_lo(yv.x), bf16_hi(yv.x), bf16_lo(yv.y), bf16_hi(yv.y),
@@ -95,6 +100,24 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int j = 0; j < R; ++j) acc[e][j] += y[e] * u[j];
     }
+  }
+  for (int w = 1; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int j = 0; j < R; ++j) red[lane][e * R + j] = acc[e][j];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int j = 0; j < R; ++j) acc[e][j] += red[lane][e * R + j];
+    }
+    __syncthreads();
+  }
+  if (wave == 0 && active) {
 #pragma unroll
     for (int e = 0; e < 8; ++e)
 #pragma unroll
@@ -130,9 +153,9 @@ extern "C" int mfnet_skinny_tn(const void* Y, int64_t ldy, const float* U, int64
   MF_CHECK_ARG(ldu >= R && ldu % 4 == 0, "skinny_tn: bad ldu");
   if (M <= 0) return MFNET_OK;
   const int64_t strips = ceil_div64(C, 512);
-  int64_t splits = ceil_div64(1024, strips);          // aim for ~1024 workgroups
+  int64_t splits = ceil_div64(256, strips);           // aim for ~256 workgroups (one per CU)
   int64_t rpb = ceil_div64(M, splits);
-  if (rpb < 32) rpb = 32;
+  if (rpb < 64) rpb = 64;
   rpb = ceil_div64(rpb, 4) * 4;
   splits = ceil_div64(M, rpb);
   dim3 grid((unsigned)strips, (unsigned)splits), block(256);
