@@ -157,6 +157,115 @@ int mfnet_argmax_chw(const float* pred, unsigned char* out, int64_t C, int64_t N
 int mfnet_minmax(const float* x, float* out, int64_t n, hipStream_t stream);
 int mfnet_scale_shift(const float* x, float* y, const float* mm, float unused, int64_t n, int mode, hipStream_t stream);
 
+/* ===================== FPN / SE-fusion / UNetFormer decoder (unetformer_mmsam.py:24-563) =====================
+ * Channels-last maps flattened to [rows = B*H*W, C]; *_dtype selects fp32 / bf16 storage per tensor. The
+ * decoder's dense contractions (1x1 convs :43-62, ConvTranspose2d k2s2 :494-516 as a GEMM with N = 4*C,
+ * 3x3 convs through mfnet_im2col3x3) run on mfnet_gemm_bf16 (act 3 = ReLU6, 4 = multiply by the ReLU6 mask
+ * of aux, 5 = ReLU6 after the residual add); the kernels below are the HBM-bound remainder. */
+
+/* per-(group, channel) sums over the P rows of each of G groups: sum [G,C] += sum_p x, sumsq += sum_p x*x
+ * (sumsq may be null). BatchNorm statistics (G = 1), F.adaptive_avg_pool2d of SqueezeAndExcitation (:262)
+ * and of FeatureRefinementHead.ca (:333). coldot: out [G,C] += sum_p a*b (gate gradients). Zero outputs first. */
+int mfnet_colsum(const void* x, int x_dtype, float* sum, float* sumsq, int64_t G, int64_t P, int64_t C, hipStream_t stream);
+int mfnet_coldot(const void* a, int a_dtype, const void* b, int b_dtype, float* out, int64_t G, int64_t P, int64_t C,
+                 hipStream_t stream);
+
+/* nn.BatchNorm2d (:27-73,126-129,508). finalize: training != 0: mean / rstd from the batch sums (biased
+ * variance), running_mean / running_var updated with `momentum` (unbiased variance), num_batches_tracked += 1;
+ * training == 0: mean / rstd from the running statistics. apply: y = act((x-mean)*rstd*gamma+beta) *
+ * chan_scale[row / rows_per_image] with act 0 none | 1 ReLU6 (ConvBNReLU) | 2 GELU; chan_scale (optional,
+ * [B,C]) is the Dropout2d mask of the segmentation head (:440); y2 is an optional second copy in another
+ * dtype. bwd_reduce: dsum [C] += sum dy', dxh [C] += sum dy'*xhat (= dbeta, dgamma) with dy' = dy * chan_scale
+ * * act'(.); bwd_apply: dx = gamma*rstd*(dy' - [training](dsum + xhat*dxh)/rows). */
+int mfnet_bn_finalize(const float* sum, const float* sumsq, float* mean, float* rstd, float* run_mean, float* run_var,
+                      int64_t* num_batches_tracked, int64_t C, int64_t n_rows, float eps, float momentum, int training,
+                      hipStream_t stream);
+int mfnet_bn_apply(const void* x, int x_dtype, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                   int act, const float* chan_scale, int64_t rows_per_image, void* y, int y_dtype, void* y2, int y2_dtype,
+                   int64_t rows, int64_t C, hipStream_t stream);
+int mfnet_bn_bwd_reduce(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, int act, const float* chan_scale, int64_t rows_per_image,
+                        float* dsum, float* dxh, int64_t rows, int64_t C, hipStream_t stream);
+int mfnet_bn_bwd_apply(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd,
+                       const float* gamma, const float* beta, int act, const float* chan_scale, int64_t rows_per_image,
+                       const float* dsum, const float* dxh, int training, void* dx, int dx_dtype, int64_t rows, int64_t C,
+                       hipStream_t stream);
+
+/* elementwise activation (0 none | 1 ReLU6 | 2 exact GELU) and its backward dx = dy * act'(ref) (nn.GELU of
+ * fpn1 :497,509; the final nn.ReLU6 of FeatureRefinementHead :353). n % 4 == 0. */
+int mfnet_act(const void* x, int x_dtype, void* y, int y_dtype, int act, int64_t n, hipStream_t stream);
+int mfnet_act_bwd(const void* dy, int dy_dtype, const void* ref, int ref_dtype, void* dx, int dx_dtype, int act, int64_t n,
+                  hipStream_t stream);
+
+/* depthwise k x k conv, zero padding (k-1)/2, x / y [B,H,W,C] fp32, w [C, k*k] (nn.Conv2d(groups=C) weight):
+ * FeatureRefinementHead.pa (k 3, bias, :329-331), SeparableConvBN (:64-73) of FRH.proj (k 3) and of
+ * GlobalLocalAttention.proj (k 8). ext != 0 folds GLA's `F.pad(out, (0,1,0,1), 'reflect')` (:192-196) into the
+ * indexing. bwd_weight ADDS into dw [C, k*k] and dbias [C] (optional). */
+int mfnet_dwconv_fwd(const float* x, const float* w, const float* bias, float* y, int64_t B, int64_t H, int64_t W, int64_t C,
+                     int64_t k, int ext, hipStream_t stream);
+int mfnet_dwconv_bwd_data(const void* dy, int dy_dtype, const float* w, float* dx, int64_t B, int64_t H, int64_t W, int64_t C,
+                          int64_t k, int ext, hipStream_t stream);
+int mfnet_dwconv_bwd_weight(const void* dy, int dy_dtype, const float* x, float* dw, float* dbias, int64_t B, int64_t H,
+                            int64_t W, int64_t C, int64_t k, int ext, hipStream_t stream);
+
+/* GlobalLocalAttention's window attention (:169-186): qkv [B*H*W, 3*heads*8] bf16 in the 1x1 qkv conv's
+ * channel order (which, head, d); 8x8 windows (H, W multiples of 8), softmax(q.k*scale +
+ * relative_position_bias_table[index(i,j)][head]).v -> out [B*H*W, heads*8] fp32. bwd writes dqkv (bf16) and
+ * ADDS the table gradient into dtable [225, heads]. Only hd = 8, ws = 8 are implemented. */
+int mfnet_gla_attn_fwd(const void* qkv, const float* table, float* out, int64_t B, int64_t H, int64_t W, int64_t heads,
+                       int64_t hd, int64_t ws, float scale, hipStream_t stream);
+int mfnet_gla_attn_bwd(const void* qkv, const float* table, const float* dout, void* dqkv, float* dtable, int64_t B,
+                       int64_t H, int64_t W, int64_t heads, int64_t hd, int64_t ws, float scale, hipStream_t stream);
+/* out = AvgPool2d((8,1),1,(3,0))(pad_bottom_reflect(o)) + AvgPool2d((1,8),1,(0,3))(pad_right_reflect(o)) + l1 + l2
+ * (:187-191; attn_x / attn_y / local); bwd returns d o (d l1 = d l2 = ds). All fp32 [B,H,W,C]. */
+int mfnet_gla_pool_fwd(const float* o, const float* l1, const float* l2, float* out, int64_t B, int64_t H, int64_t W,
+                       int64_t C, hipStream_t stream);
+int mfnet_gla_pool_bwd(const float* ds, float* d_o, int64_t B, int64_t H, int64_t W, int64_t C, hipStream_t stream);
+
+/* WF / FeatureRefinementHead fusion (:242-246,342-345): out[b,Y,X] = fw0*skip[perm(b,Y,X)] + fw1*bilinear_x2(x),
+ * fw = relu(w)/(relu(w0)+relu(w1)+eps) read from the device pointer w[2]; x [B,H/2,W/2,C] fp32. `perm`: row
+ * order of skip = number of ConvTranspose(k2,s2) GEMMs stacked above the raster grid (0 raster, 1, 2), so no
+ * pixel-shuffle pass exists. bwd: dx (fp32), dskip (skip's order), dw[2] += fusion-weight gradient; `sums` is a
+ * 2-float scratch buffer supplied by the caller. */
+int mfnet_upfuse_fwd(const float* x, const void* skip, int skip_dtype, int perm, const float* w, float eps, void* out,
+                     int out_dtype, int64_t B, int64_t H, int64_t W, int64_t C, hipStream_t stream);
+int mfnet_upfuse_bwd(const float* df, const float* x, const void* skip, int skip_dtype, int perm, const float* w, float eps,
+                     float* dx, void* dskip, int dskip_dtype, float* dw, float* sums, int64_t B, int64_t H, int64_t W,
+                     int64_t C, hipStream_t stream);
+/* final F.interpolate(bilinear, align_corners=False) by integer factor s (:455): x [B,h,w,ldx] fp32 (first ncls
+ * channels) -> logits [B,ncls,h*s,w*s] fp32 NCHW; bwd: dlogits -> dx [B,h,w,ldx] bf16 (channels >= ncls zero). */
+int mfnet_up_final_fwd(const float* x, int64_t ldx, float* logits, int64_t B, int64_t h, int64_t w, int64_t ncls, int64_t s,
+                       hipStream_t stream);
+int mfnet_up_final_bwd(const float* dlogits, void* dx, int64_t ldx, int64_t B, int64_t h, int64_t w, int64_t ncls, int64_t s,
+                       hipStream_t stream);
+/* fpn4 = nn.MaxPool2d(2,2) (:501,513): y [B,H/2,W/2,C] fp32 + arg (0..3) uint8; bwd scatters (accumulate != 0: +=). */
+int mfnet_maxpool2_fwd(const float* x, float* y, unsigned char* arg, int64_t B, int64_t H, int64_t W, int64_t C,
+                       hipStream_t stream);
+int mfnet_maxpool2_bwd(const void* dy, int dy_dtype, const unsigned char* arg, float* dx, int64_t B, int64_t H, int64_t W,
+                       int64_t C, int accumulate, hipStream_t stream);
+
+/* SqueezeAndExcitation gate (:251-266; C 256, Cr 16, biases, ReLU) and FRH channel attention (:333-337; C 64,
+ * Cr 4, no biases, relu6 != 0): z = act(W1*pooled_sum/P + b1), g = sigmoid(W2*z + b2), one block per image.
+ * bwd: dg [B,C] -> dpool [B,C] (= d pooled mean / P, the per-pixel share) and ADDS dW1, db1, dW2, db2.
+ * se_scale_sum = SEFusion (:268-281): out = rx*gx[b] + ry*gy[b]; se_bwd_apply: drx = dres*gx[b] + dpx[b], same y. */
+int mfnet_se_gate_fwd(const float* pooled_sum, int64_t P, const float* W1, const float* b1, const float* W2, const float* b2,
+                      int relu6, float* z, float* g, int64_t B, int64_t C, int64_t Cr, hipStream_t stream);
+int mfnet_se_gate_bwd(const float* dg, const float* pooled_sum, int64_t P, const float* W1, const float* W2, int relu6,
+                      const float* z, const float* g, float* dpool, float* dW1, float* db1, float* dW2, float* db2, int64_t B,
+                      int64_t C, int64_t Cr, hipStream_t stream);
+int mfnet_se_scale_sum(const void* rx, int rx_dtype, const void* ry, int ry_dtype, const float* gx, const float* gy, void* out,
+                       int out_dtype, int64_t B, int64_t P, int64_t C, hipStream_t stream);
+int mfnet_se_bwd_apply(const void* dres, int dres_dtype, const float* gx, const float* gy, const float* dpx, const float* dpy,
+                       void* drx, int drx_dtype, void* dry, int dry_dtype, int64_t B, int64_t P, int64_t C, hipStream_t stream);
+/* FRH: pc = xf*(sigmoid(dwo) + gate[b]) = pa(x)*x + ca(x)*x (:349-351); bwd: dxf = dpc*(sig+gate) (+ dpool[b]),
+ * ddwo = dpc*xf*sig*(1-sig). add3: out = a + b (+ c), gradient joins. */
+int mfnet_frh_gate_fwd(const float* xf, const float* dwo, const float* gate, float* pc, int64_t B, int64_t P, int64_t C,
+                       hipStream_t stream);
+int mfnet_frh_gate_bwd(const float* dpc, const float* xf, const float* dwo, const float* gate, const float* dpool, float* dxf,
+                       float* ddwo, int64_t B, int64_t P, int64_t C, hipStream_t stream);
+int mfnet_add3(const void* a, int a_dtype, const void* b, int b_dtype, const void* c, int c_dtype, void* out, int out_dtype,
+               int64_t n, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

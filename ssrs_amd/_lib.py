@@ -57,6 +57,35 @@ _SIGS = {
     "mfnet_add_bf16": [P, P, P, I64, P],
     "mfnet_bias_grad": [P, I64, P, I64, I64, P],
     "mfnet_transpose_bf16": [P, I64, P, I64, I64, I64, P],
+    # ---- FPN / SE-fusion / UNetFormer decoder (csrc/decoder.hip)
+    "mfnet_colsum": [P, I, P, P, I64, I64, I64, P],
+    "mfnet_coldot": [P, I, P, I, P, I64, I64, I64, P],
+    "mfnet_bn_finalize": [P, P, P, P, P, P, P, I64, I64, F, F, I, P],
+    "mfnet_bn_apply": [P, I, P, P, P, P, I, P, I64, P, I, P, I, I64, I64, P],
+    "mfnet_bn_bwd_reduce": [P, I, P, I, P, P, P, P, I, P, I64, P, P, I64, I64, P],
+    "mfnet_bn_bwd_apply": [P, I, P, I, P, P, P, P, I, P, I64, P, P, I, P, I, I64, I64, P],
+    "mfnet_act": [P, I, P, I, I, I64, P],
+    "mfnet_act_bwd": [P, I, P, I, P, I, I, I64, P],
+    "mfnet_dwconv_fwd": [P, P, P, P, I64, I64, I64, I64, I64, I, P],
+    "mfnet_dwconv_bwd_data": [P, I, P, P, I64, I64, I64, I64, I64, I, P],
+    "mfnet_dwconv_bwd_weight": [P, I, P, P, P, I64, I64, I64, I64, I64, I, P],
+    "mfnet_gla_attn_fwd": [P, P, P, I64, I64, I64, I64, I64, I64, F, P],
+    "mfnet_gla_attn_bwd": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, F, P],
+    "mfnet_gla_pool_fwd": [P, P, P, P, I64, I64, I64, I64, P],
+    "mfnet_gla_pool_bwd": [P, P, I64, I64, I64, I64, P],
+    "mfnet_upfuse_fwd": [P, P, I, I, P, F, P, I, I64, I64, I64, I64, P],
+    "mfnet_upfuse_bwd": [P, P, P, I, I, P, F, P, P, I, P, P, I64, I64, I64, I64, P],
+    "mfnet_up_final_fwd": [P, I64, P, I64, I64, I64, I64, I64, P],
+    "mfnet_up_final_bwd": [P, P, I64, I64, I64, I64, I64, I64, P],
+    "mfnet_maxpool2_fwd": [P, P, P, I64, I64, I64, I64, P],
+    "mfnet_maxpool2_bwd": [P, I, P, P, I64, I64, I64, I64, I, P],
+    "mfnet_se_gate_fwd": [P, I64, P, P, P, P, I, P, P, I64, I64, I64, P],
+    "mfnet_se_gate_bwd": [P, P, I64, P, P, I, P, P, P, P, P, P, P, I64, I64, I64, P],
+    "mfnet_se_scale_sum": [P, I, P, I, P, P, P, I, I64, I64, I64, P],
+    "mfnet_se_bwd_apply": [P, I, P, P, P, P, P, I, P, I, I64, I64, I64, P],
+    "mfnet_frh_gate_fwd": [P, P, P, P, I64, I64, I64, P],
+    "mfnet_frh_gate_bwd": [P, P, P, P, P, P, P, I64, I64, I64, P],
+    "mfnet_add3": [P, I, P, I, P, I, P, I, I64, P],
 }
 
 

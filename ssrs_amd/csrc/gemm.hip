@@ -32,7 +32,7 @@ struct GemmParams {
   const float* bias;
   const float* U; int64_t ldu;
   const float* V; int64_t v_group_stride; int64_t rows_per_group; int n_groups; int R; float lr_scale;
-  int act;                              // 0 none, 1 gelu, 2 multiply by gelu'(aux)
+  int act;                              // 0 none, 1 gelu, 2 *gelu'(aux), 3 relu6, 4 *relu6'(aux = relu6 output), 5 relu6 AFTER the residual add
   const bf16_t* aux; int64_t ldaux;
   bf16_t* out_pre; int64_t ldpre;
   const float* residual; int64_t ldres; int64_t res_row_mod;
@@ -212,15 +212,27 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     if (p.act == 1) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) v[i] = gelu_f(v[i]);
-    } else if (p.act == 2) {
+    } else if (p.act == 2 || p.act == 4) {
       const u32x4_t* ap = reinterpret_cast<const u32x4_t*>(p.aux + m * p.ldaux + nb);
       const u32x4_t a0 = ap[0], a1 = ap[1];
       const unsigned int aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      if (p.act == 2) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        v[2 * i] *= gelu_grad_f(bf16_lo(aw[i]));
-        v[2 * i + 1] *= gelu_grad_f(bf16_hi(aw[i]));
+        for (int i = 0; i < 8; ++i) {
+          v[2 * i] *= gelu_grad_f(bf16_lo(aw[i]));
+          v[2 * i + 1] *= gelu_grad_f(bf16_hi(aw[i]));
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float lo = bf16_lo(aw[i]), hi = bf16_hi(aw[i]);
+          v[2 * i] = (lo > 0.f && lo < 6.f) ? v[2 * i] : 0.f;
+          v[2 * i + 1] = (hi > 0.f && hi < 6.f) ? v[2 * i + 1] : 0.f;
+        }
       }
+    } else if (p.act == 3) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = fminf(fmaxf(v[i], 0.f), 6.f);
     }
     if (p.residual) {
       const int64_t rr = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
@@ -230,6 +242,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
         const float4 r4 = rp[i];
         v[4 * i] += r4.x; v[4 * i + 1] += r4.y; v[4 * i + 2] += r4.z; v[4 * i + 3] += r4.w;
       }
+    }
+    if (p.act == 5) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = fminf(fmaxf(v[i], 0.f), 6.f);
     }
     if (p.out_dtype == MFNET_BF16) {
       u32x4_t w0, w1;
@@ -259,9 +275,9 @@ extern "C" int mfnet_gemm_bf16(const void* A, int64_t lda, const void* W, int64_
   MF_CHECK_ARG(ldc >= N && ldc % 8 == 0, "gemm_bf16: bad ldc");
   MF_CHECK_ARG(((uintptr_t)A | (uintptr_t)W | (uintptr_t)out) % 16 == 0, "gemm_bf16: operands must be 16-byte aligned");
   MF_CHECK_ARG(out_dtype == MFNET_BF16 || out_dtype == MFNET_F32, "gemm_bf16: bad out dtype");
-  MF_CHECK_ARG(act >= 0 && act <= 2, "gemm_bf16: bad act");
-  MF_CHECK_ARG(act != 2 || (aux && ldaux >= N && ldaux % 8 == 0), "gemm_bf16: act=2 needs aux");
-  MF_CHECK_ARG(!out_pre || (act != 2 && ldpre >= N && ldpre % 8 == 0), "gemm_bf16: bad out_pre");
+  MF_CHECK_ARG(act >= 0 && act <= 5, "gemm_bf16: bad act");
+  MF_CHECK_ARG((act != 2 && act != 4) || (aux && ldaux >= N && ldaux % 8 == 0), "gemm_bf16: act=2/4 needs aux");
+  MF_CHECK_ARG(!out_pre || (act != 2 && act != 4 && ldpre >= N && ldpre % 8 == 0), "gemm_bf16: bad out_pre");
   MF_CHECK_ARG(!residual || (ldres >= N && ldres % 4 == 0), "gemm_bf16: bad residual ld");
   if (U) {
     MF_CHECK_ARG(V && R > 0 && R <= GEMM_MAX_R && R % 4 == 0 && ldu >= R && ldu % 4 == 0, "gemm_bf16: bad low-rank args (R=%d)", R);

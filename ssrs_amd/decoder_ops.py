@@ -1,0 +1,487 @@
+"""FPN / SE-fusion / UNetFormer decoder on the gfx950 kernels (csrc/decoder.hip + the bf16 GEMM).
+
+Everything runs on channels-last maps flattened to [rows, C]; each reference module is one
+torch.autograd.Function with a hand-written backward (reference: unetformer_mmsam.py, cited per class).
+
+Layout trick for the FPN: ConvTranspose2d(k=2, s=2) is a GEMM with N = 4*C whose output row m=(b,y,x)
+holds the four sub-pixels (dy,dx) of that input pixel. Nothing downstream of the FPN needs the pixels in
+raster order until the WF / FRH fusion (LayerNorm / BatchNorm / GELU are per pixel or per channel, the
+SE pool is a sum over all pixels, the decoder's pre_conv is 1x1), so the pixel-shuffle is never run: the
+fusion kernel reads its skip operand through the "un-shuffled" row order (perm = number of stacked
+ConvTransposes).
+
+Precision: bf16 MFMA operands with fp32 accumulation for every contraction, fp32 for BatchNorm
+statistics, residual streams, depthwise convs, window attention and pooling.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_GELU, ACT_NONE, ACT_RELU6
+
+BF = torch.bfloat16
+F32 = torch.float32
+
+
+# ---------------------------------------------------------------------------------------------- helpers
+def _wb(w2d: torch.Tensor) -> torch.Tensor:
+    """bf16 copy of a trainable [N, K] weight (rebuilt every step: it changes every step)."""
+    w2d = w2d.detach().contiguous()
+    return ops.cast(w2d, BF) if w2d.numel() % 8 == 0 else w2d.to(BF)
+
+
+def _w3(w):        # [O, I, 3, 3] -> [O, 9*I], k = tap*I + i (im2col3x3 order)
+    return w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+
+
+def _w3_grad(g, w):  # [O, 9*I] -> [O, I, 3, 3]
+    O, I = w.shape[0], w.shape[1]
+    return g.view(O, 3, 3, I).permute(0, 3, 1, 2).contiguous()
+
+
+def _bn(x, bn: nn.BatchNorm2d, training, act=ACT_NONE, out_dtype=F32, out2_dtype=None, chan_scale=None, rpi=0):
+    if training and bn.momentum is None:
+        raise NotImplementedError("BatchNorm with cumulative moving average (momentum=None) is not used by MFNet")
+    return ops.bn_forward(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked if training else None,
+                          training, bn.eps, bn.momentum if bn.momentum is not None else 0.1, act, chan_scale, rpi, out_dtype, out2_dtype)
+
+
+def _bn_bwd(dy, x, mean, rstd, bn, training, act=ACT_NONE, dx_dtype=F32, chan_scale=None, rpi=0):
+    return ops.bn_backward(dy, x, mean, rstd, bn.weight, bn.bias, training, act, chan_scale, rpi, dx_dtype)
+
+
+def _conv3_fwd(x_bf, w, B, H, W):
+    cols = ops.im2col3x3(x_bf, B, H, W)
+    return ops.gemm(cols, _wb(_w3(w)), out_dtype=F32), cols
+
+
+def _conv3_bwd(dy_bf, cols, w, B, H, W):
+    """-> (dx fp32 [M, I], dW like w)."""
+    dcols = ops.gemm(dy_bf, _wb(_w3(w).t()))
+    dx = ops.col2im3x3(dcols, B, H, W, w.shape[1])
+    return dx, _w3_grad(ops.gemm_tn(dy_bf, cols), w)
+
+
+def _w2(w):          # 1x1 conv weight [O, I, 1, 1] -> [O, I]
+    return w.detach().reshape(w.shape[0], w.shape[1])
+
+
+def _grads(plist, gd):
+    return tuple(gd.get(id(p)) for p in plist)
+
+
+def _put(gd, p, g):
+    g = g.reshape(p.shape)
+    gd[id(p)] = g if id(p) not in gd else gd[id(p)] + g
+
+
+# ---------------------------------------------------------------------------------------------- FPN + SEFusion
+def _ct_w(w):        # ConvTranspose2d weight [Ci, Co, 2, 2] -> GEMM weight [(dy,dx,co), ci]
+    return w.detach().permute(2, 3, 1, 0).reshape(4 * w.shape[1], w.shape[0])
+
+
+def _ct_wT(w):       # -> [ci, (dy,dx,co)] for the dgrad GEMM
+    return w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], 4 * w.shape[1])
+
+
+def _ct_grad(g, w):  # [(dy,dx,co), ci] -> [Ci, Co, 2, 2]
+    return g.view(2, 2, w.shape[1], w.shape[0]).permute(3, 2, 0, 1).contiguous()
+
+
+def fpn_fusion_params(model):
+    ps = []
+    for m in "xy":
+        f1, f2 = getattr(model, f"fpn1{m}"), getattr(model, f"fpn2{m}")
+        norm = f1[1].ln if m == "x" else f1[1]
+        ps += [f1[0].weight, f1[0].bias, norm.weight, norm.bias, f1[3].weight, f1[3].bias, f2[0].weight, f2[0].bias]
+    for i in (1, 2, 3, 4):
+        fu = getattr(model, f"fusion{i}")
+        for se in (fu.se_rgb, fu.se_depth):
+            ps += [se.fc[0].weight, se.fc[0].bias, se.fc[2].weight, se.fc[2].bias]
+    return ps
+
+
+class FpnFusionFn(torch.autograd.Function):
+    """deep [2B, h, w, 256] fp32 (RGB images first) -> res1 (perm 2), res2 (perm 1), res3, res4, all bf16
+    [rows, 256]: fpn1..4{x,y} (unetformer_mmsam.py:494-516,545-552) + fusion1..4 (:251-281,553-556)."""
+
+    @staticmethod
+    def forward(ctx, deep, model, training, *plist):
+        twoB, h, w, C = deep.shape
+        B = twoB // 2
+        M3 = B * h * w
+        d2 = deep.reshape(2 * M3, C).contiguous()
+        db = ops.cast(d2, BF)
+        sv = {"B": B, "h": h, "w": w, "db": db, "training": training}
+        r = {}
+        for mi, m in enumerate("xy"):
+            f1, f2 = getattr(model, f"fpn1{m}"), getattr(model, f"fpn2{m}")
+            dm = db[mi * M3:(mi + 1) * M3]
+            t1 = ops.gemm(dm, _wb(_ct_w(f1[0].weight)), bias=f1[0].bias.detach().repeat(4), out_dtype=F32).view(4 * M3, C)
+            if m == "x":
+                n1, mean, rstd = ops.layernorm_fwd(t1, f1[1].ln.weight, f1[1].ln.bias, f1[1].ln.eps, out_dtype=BF)
+            else:
+                n1, _, mean, rstd = _bn(t1, f1[1], training, out_dtype=BF)
+            a1 = ops.act(n1, ACT_GELU)
+            r1 = ops.gemm(a1, _wb(_ct_w(f1[3].weight)), bias=f1[3].bias.detach().repeat(4)).view(16 * M3, C)
+            r2 = ops.gemm(dm, _wb(_ct_w(f2[0].weight)), bias=f2[0].bias.detach().repeat(4)).view(4 * M3, C)
+            r3 = d2[mi * M3:(mi + 1) * M3]
+            r4, arg = ops.maxpool2_fwd(r3, B, h, w)
+            r[m] = (r1, r2, r3, r4)
+            sv[m] = dict(t1=t1, n1=n1, mean=mean, rstd=rstd, a1=a1, arg=arg)
+        outs = []
+        P = (16 * h * w, 4 * h * w, h * w, (h // 2) * (w // 2))
+        for i in range(4):
+            fu = getattr(model, f"fusion{i + 1}")
+            gate = {}
+            for m, se in (("x", fu.se_rgb), ("y", fu.se_depth)):
+                s, _ = ops.colsum(r[m][i], B, P[i])
+                z, g = ops.se_gate_fwd(s, P[i], _w2(se.fc[0].weight), se.fc[0].bias, _w2(se.fc[2].weight), se.fc[2].bias, False)
+                gate[m] = (s, z, g)
+            outs.append(ops.se_scale_sum(r["x"][i], r["y"][i], gate["x"][2], gate["y"][2], B, P[i]))
+            sv[f"f{i}"] = gate
+        sv["r"], sv["P"] = r, P
+        ctx.sv, ctx.model, ctx.plist = sv, model, plist
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dres):
+        sv, model, plist = ctx.sv, ctx.model, ctx.plist
+        B, h, w, db, training, r, P = sv["B"], sv["h"], sv["w"], sv["db"], sv["training"], sv["r"], sv["P"]
+        M3 = B * h * w
+        C = db.shape[1]
+        gd = {}
+        ddeep = torch.empty((2 * M3, C), dtype=F32, device=db.device)
+        dr = {"x": [None] * 4, "y": [None] * 4}
+        for i in range(4):
+            fu = getattr(model, f"fusion{i + 1}")
+            gate = sv[f"f{i}"]
+            d = dres[i].contiguous()
+            dp = {}
+            for m, se in (("x", fu.se_rgb), ("y", fu.se_depth)):
+                s, z, g = gate[m]
+                dg = ops.coldot(d, r[m][i], B, P[i])
+                dpool, dW1, db1, dW2, db2 = ops.se_gate_bwd(dg, s, P[i], _w2(se.fc[0].weight), _w2(se.fc[2].weight), False, z, g, True)
+                _put(gd, se.fc[0].weight, dW1); _put(gd, se.fc[0].bias, db1)
+                _put(gd, se.fc[2].weight, dW2); _put(gd, se.fc[2].bias, db2)
+                dp[m] = dpool
+            if i == 2:      # fpn3 = identity: its gradient initialises d(deep)
+                ops.se_bwd_apply(d, gate["x"][2], gate["y"][2], dp["x"], dp["y"], B, P[i], out_x=ddeep[:M3], out_y=ddeep[M3:])
+            else:
+                dt = F32 if i == 3 else BF
+                dr["x"][i], dr["y"][i] = ops.se_bwd_apply(d, gate["x"][2], gate["y"][2], dp["x"], dp["y"], B, P[i], dt, dt)
+        for mi, m in enumerate("xy"):
+            f1, f2 = getattr(model, f"fpn1{m}"), getattr(model, f"fpn2{m}")
+            s = sv[m]
+            dm = db[mi * M3:(mi + 1) * M3]
+            dd = ddeep[mi * M3:(mi + 1) * M3]
+            ops.maxpool2_bwd(dr[m][3], s["arg"], dd, B, h, w, accumulate=True)
+            # fpn2
+            dY = dr[m][1].view(M3, 4 * C)
+            ops.gemm(dY, _wb(_ct_wT(f2[0].weight)), residual=dd, out=dd)
+            _put(gd, f2[0].weight, _ct_grad(ops.gemm_tn(dY, dm), f2[0].weight))
+            _put(gd, f2[0].bias, ops.bias_grad(dY.view(4 * M3, C)))
+            # fpn1: second ConvT -> GELU -> norm -> first ConvT
+            dY2 = dr[m][0].view(4 * M3, 4 * C)
+            dn1 = ops.gemm(dY2, _wb(_ct_wT(f1[3].weight)), act=2, aux=s["n1"])
+            _put(gd, f1[3].weight, _ct_grad(ops.gemm_tn(dY2, s["a1"]), f1[3].weight))
+            _put(gd, f1[3].bias, ops.bias_grad(dY2.view(16 * M3, C)))
+            if m == "x":
+                ln = f1[1].ln
+                dgam = torch.zeros(C, dtype=F32, device=db.device)
+                dbet = torch.zeros(C, dtype=F32, device=db.device)
+                _, dt1 = ops.layernorm_bwd(dn1, s["t1"], s["mean"], s["rstd"], ln.weight, want_f32=False, want_bf16=True, dgamma=dgam, dbeta=dbet)
+                _put(gd, ln.weight, dgam); _put(gd, ln.bias, dbet)
+            else:
+                dt1, dgam, dbet = _bn_bwd(dn1, s["t1"], s["mean"], s["rstd"], f1[1], training, dx_dtype=BF)
+                _put(gd, f1[1].weight, dgam); _put(gd, f1[1].bias, dbet)
+            dY1 = dt1.view(M3, 4 * C)
+            ops.gemm(dY1, _wb(_ct_wT(f1[0].weight)), residual=dd, out=dd)
+            _put(gd, f1[0].weight, _ct_grad(ops.gemm_tn(dY1, dm), f1[0].weight))
+            _put(gd, f1[0].bias, ops.bias_grad(dY1.view(4 * M3, C)))
+        return (ddeep.view(2 * B, h, w, C), None, None) + _grads(plist, gd)
+
+
+# ---------------------------------------------------------------------------------------------- ConvBN 1x1 (decoder.pre_conv)
+def convbn_params(seq):
+    return [seq[0].weight, seq[1].weight, seq[1].bias]
+
+
+class ConvBN1x1Fn(torch.autograd.Function):
+    """ConvBN(kernel 1) (unetformer_mmsam.py:43-51): x bf16 [M, Cin] -> fp32 [M, Cout]."""
+
+    @staticmethod
+    def forward(ctx, x, seq, training, *plist):
+        c = ops.gemm(x, _wb(_w2(seq[0].weight)), out_dtype=F32)
+        y, _, mean, rstd = _bn(c, seq[1], training)
+        ctx.save_for_backward(x, c, mean, rstd)
+        ctx.seq, ctx.training, ctx.plist = seq, training, plist
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, c, mean, rstd = ctx.saved_tensors
+        seq = ctx.seq
+        dc, dg, dbt = _bn_bwd(dy.contiguous(), c, mean, rstd, seq[1], ctx.training, dx_dtype=BF)
+        gd = {}
+        _put(gd, seq[0].weight, ops.gemm_tn(dc, x)); _put(gd, seq[1].weight, dg); _put(gd, seq[1].bias, dbt)
+        dx = ops.gemm(dc, _wb(_w2(seq[0].weight).t()))
+        return (dx, None, None) + _grads(ctx.plist, gd)
+
+
+# ---------------------------------------------------------------------------------------------- Block (GLA + Mlp)
+def block_params(blk):
+    a = blk.attn
+    return [blk.norm1.weight, blk.norm1.bias, a.qkv[0].weight, a.local1[0].weight, a.local1[1].weight, a.local1[1].bias,
+            a.local2[0].weight, a.local2[1].weight, a.local2[1].bias, a.proj[0].weight, a.proj[1].weight, a.proj[1].bias,
+            a.proj[2].weight, a.relative_position_bias_table, blk.norm2.weight, blk.norm2.bias,
+            blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias]
+
+
+class BlockFn(torch.autograd.Function):
+    """Block (unetformer_mmsam.py:200-217) = x + GlobalLocalAttention(BN(x)) (:105-198), then + Mlp(BN(.))
+    (:86-102). x fp32 [B*H*W, C] -> fp32."""
+
+    @staticmethod
+    def forward(ctx, x, blk, geom, training, *plist):
+        B, H, W = geom
+        a = blk.attn
+        x = x.contiguous()
+        heads, ws = a.num_heads, a.ws
+        if H % ws or W % ws:
+            raise NotImplementedError(f"GlobalLocalAttention on a {H}x{W} map: the HIP path needs multiples of the {ws}x{ws} window "
+                                      "(input tiles that are multiples of 256 pixels); the reflect-pad branch is not implemented")
+        n1b, _, m1, r1 = _bn(x, blk.norm1, training, out_dtype=BF)
+        c1, cols = _conv3_fwd(n1b, a.local1[0].weight, B, H, W)
+        l1, _, ml1, rl1 = _bn(c1, a.local1[1], training)
+        c2 = ops.gemm(n1b, _wb(_w2(a.local2[0].weight)), out_dtype=F32)
+        l2, _, ml2, rl2 = _bn(c2, a.local2[1], training)
+        qkv = ops.gemm(n1b, _wb(_w2(a.qkv[0].weight)))
+        table = a.relative_position_bias_table.detach().contiguous()
+        o = ops.gla_attn_fwd(qkv, table, B, H, W, heads, a.scale)
+        s = ops.gla_pool_fwd(o, l1, l2, B, H, W)
+        k = a.proj[0].weight.shape[-1]
+        dwo = ops.dwconv_fwd(s, a.proj[0].weight.detach().reshape(-1, k * k), None, B, H, W, k, True)
+        pb, _, mp, rp = _bn(dwo, a.proj[1], training, out_dtype=BF)
+        x1 = ops.gemm(pb, _wb(_w2(a.proj[2].weight)), residual=x, out_dtype=F32)
+        n2b, _, m2, r2 = _bn(x1, blk.norm2, training, out_dtype=BF)
+        hid = ops.gemm(n2b, _wb(_w2(blk.mlp.fc1.weight)), bias=blk.mlp.fc1.bias, act=3)
+        x2 = ops.gemm(hid, _wb(_w2(blk.mlp.fc2.weight)), bias=blk.mlp.fc2.bias, residual=x1, out_dtype=F32)
+        ctx.save_for_backward(x, m1, r1, n1b, cols, c1, ml1, rl1, c2, ml2, rl2, qkv, s, dwo, mp, rp, pb, x1, m2, r2, n2b, hid)
+        ctx.blk, ctx.geom, ctx.training, ctx.plist = blk, geom, training, plist
+        return x2
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x, m1, r1, n1b, cols, c1, ml1, rl1, c2, ml2, rl2, qkv, s, dwo, mp, rp, pb, x1, m2, r2, n2b, hid) = ctx.saved_tensors
+        blk, (B, H, W), training = ctx.blk, ctx.geom, ctx.training
+        a, mlp = blk.attn, blk.mlp
+        gd = {}
+        dout = dout.contiguous()
+        d_bf = ops.cast(dout, BF)
+        # ---- Mlp branch
+        dhid = ops.gemm(d_bf, _wb(_w2(mlp.fc2.weight).t()), act=4, aux=hid)
+        _put(gd, mlp.fc2.weight, ops.gemm_tn(d_bf, hid)); _put(gd, mlp.fc2.bias, ops.bias_grad(d_bf))
+        dn2 = ops.gemm(dhid, _wb(_w2(mlp.fc1.weight).t()))
+        _put(gd, mlp.fc1.weight, ops.gemm_tn(dhid, n2b)); _put(gd, mlp.fc1.bias, ops.bias_grad(dhid))
+        dx1b, dg, dbt = _bn_bwd(dn2, x1, m2, r2, blk.norm2, training)
+        _put(gd, blk.norm2.weight, dg); _put(gd, blk.norm2.bias, dbt)
+        dx1 = ops.add3(dout, dx1b)
+        # ---- attention branch: x1 = x + proj1x1(BN(dw8x8(pool(o) + local)))
+        dx1_bf = ops.cast(dx1, BF)
+        dpb = ops.gemm(dx1_bf, _wb(_w2(a.proj[2].weight).t()))
+        _put(gd, a.proj[2].weight, ops.gemm_tn(dx1_bf, pb))
+        ddwo, dg, dbt = _bn_bwd(dpb, dwo, mp, rp, a.proj[1], training)
+        _put(gd, a.proj[1].weight, dg); _put(gd, a.proj[1].bias, dbt)
+        k = a.proj[0].weight.shape[-1]
+        ds, dwdw, _ = ops.dwconv_bwd(ddwo, s, a.proj[0].weight.detach().reshape(-1, k * k), B, H, W, k, True)
+        _put(gd, a.proj[0].weight, dwdw)
+        d_o = ops.gla_pool_bwd(ds, B, H, W)
+        table = a.relative_position_bias_table.detach().contiguous()
+        dqkv, dtable = ops.gla_attn_bwd(qkv, table, d_o, B, H, W, a.num_heads, a.scale)
+        _put(gd, a.relative_position_bias_table, dtable)
+        dc1, dg, dbt = _bn_bwd(ds, c1, ml1, rl1, a.local1[1], training, dx_dtype=BF)
+        _put(gd, a.local1[1].weight, dg); _put(gd, a.local1[1].bias, dbt)
+        dc2, dg, dbt = _bn_bwd(ds, c2, ml2, rl2, a.local2[1], training, dx_dtype=BF)
+        _put(gd, a.local2[1].weight, dg); _put(gd, a.local2[1].bias, dbt)
+        dn1, dW3 = _conv3_bwd(dc1, cols, a.local1[0].weight, B, H, W)
+        _put(gd, a.local1[0].weight, dW3)
+        ops.gemm(dqkv, _wb(_w2(a.qkv[0].weight).t()), residual=dn1, out=dn1)
+        ops.gemm(dc2, _wb(_w2(a.local2[0].weight).t()), residual=dn1, out=dn1)
+        _put(gd, a.qkv[0].weight, ops.gemm_tn(dqkv, n1b)); _put(gd, a.local2[0].weight, ops.gemm_tn(dc2, n1b))
+        dxb, dg, dbt = _bn_bwd(dn1, x, m1, r1, blk.norm1, training)
+        _put(gd, blk.norm1.weight, dg); _put(gd, blk.norm1.bias, dbt)
+        dx = ops.add3(dx1, dxb)
+        return (dx, None, None, None) + _grads(ctx.plist, gd)
+
+
+# ---------------------------------------------------------------------------------------------- WF / FRH
+def wf_params(m):
+    return [m.pre_conv[0].weight, m.weights, m.post_conv[0].weight, m.post_conv[1].weight, m.post_conv[1].bias]
+
+
+def _fuse_fwd(x, res, perm, m, geom, training, out2_dtype=None):
+    B, H, W = geom
+    skip = ops.gemm(res, _wb(_w2(m.pre_conv[0].weight)))
+    f = ops.upfuse_fwd(x, skip, perm, m.weights.detach(), m.eps, B, H, W)
+    c, cols = _conv3_fwd(f, m.post_conv[0].weight, B, H, W)
+    y, y2, mean, rstd = _bn(c, m.post_conv[1], training, act=ACT_RELU6, out2_dtype=out2_dtype)
+    return y, y2, (skip, cols, c, mean, rstd)
+
+
+def _fuse_bwd(dy, x, res, perm, m, geom, training, saved, gd):
+    B, H, W = geom
+    skip, cols, c, mean, rstd = saved
+    dc, dg, dbt = _bn_bwd(dy, c, mean, rstd, m.post_conv[1], training, act=ACT_RELU6, dx_dtype=BF)
+    _put(gd, m.post_conv[1].weight, dg); _put(gd, m.post_conv[1].bias, dbt)
+    df, dW3 = _conv3_bwd(dc, cols, m.post_conv[0].weight, B, H, W)
+    _put(gd, m.post_conv[0].weight, dW3)
+    dx, dskip, dw = ops.upfuse_bwd(df, x, skip, perm, m.weights.detach(), m.eps, B, H, W)
+    _put(gd, m.weights, dw)
+    dres = ops.gemm(dskip, _wb(_w2(m.pre_conv[0].weight).t()))
+    _put(gd, m.pre_conv[0].weight, ops.gemm_tn(dskip, res))
+    return dx, dres
+
+
+class WFFn(torch.autograd.Function):
+    """WF (unetformer_mmsam.py:233-248): x fp32 [B*(H/2)*(W/2), C], res bf16 [B*H*W, Cin] (row order
+    `perm`) -> ConvBNReLU6(fw0*pre_conv(res) + fw1*up2(x)) fp32 [B*H*W, C]."""
+
+    @staticmethod
+    def forward(ctx, x, res, m, perm, geom, training, *plist):
+        x, res = x.contiguous(), res.contiguous()
+        y, _, saved = _fuse_fwd(x, res, perm, m, geom, training)
+        ctx.save_for_backward(x, res, *saved)
+        ctx.m, ctx.perm, ctx.geom, ctx.training, ctx.plist = m, perm, geom, training, plist
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, res, *saved = ctx.saved_tensors
+        gd = {}
+        dx, dres = _fuse_bwd(dy.contiguous(), x, res, ctx.perm, ctx.m, ctx.geom, ctx.training, saved, gd)
+        return (dx, dres, None, None, None, None) + _grads(ctx.plist, gd)
+
+
+def frh_params(m):
+    return wf_params(m) + [m.pa[0].weight, m.pa[0].bias, m.ca[1][0].weight, m.ca[3][0].weight, m.shortcut[0].weight,
+                           m.shortcut[1].weight, m.shortcut[1].bias, m.proj[0].weight, m.proj[1].weight, m.proj[1].bias, m.proj[2].weight]
+
+
+class FRHFn(torch.autograd.Function):
+    """FeatureRefinementHead (unetformer_mmsam.py:320-354) -> bf16 [B*H*W, C]."""
+
+    @staticmethod
+    def forward(ctx, x, res, m, perm, geom, training, *plist):
+        B, H, W = geom
+        P = H * W
+        x, res = x.contiguous(), res.contiguous()
+        xf, xfb, saved = _fuse_fwd(x, res, perm, m, geom, training, out2_dtype=BF)
+        csc = ops.gemm(xfb, _wb(_w2(m.shortcut[0].weight)), out_dtype=F32)
+        sc, _, msc, rsc = _bn(csc, m.shortcut[1], training)
+        dwo = ops.dwconv_fwd(xf, m.pa[0].weight.detach().reshape(-1, 9), m.pa[0].bias, B, H, W, 3, False)
+        pool, _ = ops.colsum(xf, B, P)
+        z, g = ops.se_gate_fwd(pool, P, _w2(m.ca[1][0].weight), None, _w2(m.ca[3][0].weight), None, True)
+        pc = ops.frh_gate_fwd(xf, dwo, g, B, P)
+        dw2 = ops.dwconv_fwd(pc, m.proj[0].weight.detach().reshape(-1, 9), None, B, H, W, 3, False)
+        pb, _, mp, rp = _bn(dw2, m.proj[1], training, out_dtype=BF)
+        out = ops.gemm(pb, _wb(_w2(m.proj[2].weight)), residual=sc, act=5)
+        ctx.save_for_backward(x, res, *saved, xf, xfb, csc, msc, rsc, dwo, pool, z, g, pc, dw2, mp, rp, pb, out)
+        ctx.m, ctx.perm, ctx.geom, ctx.training, ctx.plist = m, perm, geom, training, plist
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        t = ctx.saved_tensors
+        x, res, saved = t[0], t[1], t[2:7]
+        xf, xfb, csc, msc, rsc, dwo, pool, z, g, pc, dw2, mp, rp, pb, out = t[7:]
+        m, (B, H, W), training = ctx.m, ctx.geom, ctx.training
+        P = H * W
+        gd = {}
+        dz = ops.act_bwd(dout.contiguous(), out, ACT_RELU6)                       # through the final ReLU6
+        dpb = ops.gemm(dz, _wb(_w2(m.proj[2].weight).t()))
+        _put(gd, m.proj[2].weight, ops.gemm_tn(dz, pb))
+        ddw2, dg, dbt = _bn_bwd(dpb, dw2, mp, rp, m.proj[1], training)
+        _put(gd, m.proj[1].weight, dg); _put(gd, m.proj[1].bias, dbt)
+        dpc, dwp, _ = ops.dwconv_bwd(ddw2, pc, m.proj[0].weight.detach().reshape(-1, 9), B, H, W, 3, False)
+        _put(gd, m.proj[0].weight, dwp)
+        dgate = ops.coldot(dpc, xf, B, P)
+        dpool, dW1, _, dW2, _ = ops.se_gate_bwd(dgate, pool, P, _w2(m.ca[1][0].weight), _w2(m.ca[3][0].weight), True, z, g, False)
+        _put(gd, m.ca[1][0].weight, dW1); _put(gd, m.ca[3][0].weight, dW2)
+        dxf, ddwo = ops.frh_gate_bwd(dpc, xf, dwo, g, dpool, B, P)
+        dxf2, dwpa, dbpa = ops.dwconv_bwd(ddwo, xf, m.pa[0].weight.detach().reshape(-1, 9), B, H, W, 3, False, want_bias=True)
+        _put(gd, m.pa[0].weight, dwpa); _put(gd, m.pa[0].bias, dbpa)
+        dcsc, dg, dbt = _bn_bwd(dz, csc, msc, rsc, m.shortcut[1], training, dx_dtype=BF)
+        _put(gd, m.shortcut[1].weight, dg); _put(gd, m.shortcut[1].bias, dbt)
+        _put(gd, m.shortcut[0].weight, ops.gemm_tn(dcsc, xfb))
+        dxf = ops.add3(dxf, dxf2)
+        ops.gemm(dcsc, _wb(_w2(m.shortcut[0].weight).t()), residual=dxf, out=dxf)
+        dx, dres = _fuse_bwd(dxf, x, res, ctx.perm, m, ctx.geom, training, saved, gd)
+        return (dx, dres, None, None, None, None) + _grads(ctx.plist, gd)
+
+
+# ---------------------------------------------------------------------------------------------- segmentation head
+NCLS_PAD = 32      # class maps are computed 32 wide: GEMM N % 16 == 0 forward and K % 32 == 0 in the dgrad
+
+
+def seghead_params(head):
+    return [head[0][0].weight, head[0][1].weight, head[0][1].bias, head[2][0].weight]
+
+
+class SegHeadFn(torch.autograd.Function):
+    """segmentation_head + final bilinear upsample (unetformer_mmsam.py:439-441,454-455): x bf16
+    [B*H*W, C] -> logits fp32 [B, ncls, s*H, s*W]. drop_mask [B, C] of {0, 1/(1-p)} = Dropout2d."""
+
+    @staticmethod
+    def forward(ctx, x, head, geom, scale, drop_mask, training, *plist):
+        B, H, W = geom
+        x = x.contiguous()
+        wcls = head[2][0].weight
+        ncls = wcls.shape[0]
+        if ncls > NCLS_PAD:
+            raise NotImplementedError(f"num_classes > {NCLS_PAD}")
+        c, cols = _conv3_fwd(x, head[0][0].weight, B, H, W)
+        hb, _, mean, rstd = _bn(c, head[0][1], training, act=ACT_RELU6, out_dtype=BF, chan_scale=drop_mask, rpi=H * W)
+        wp = torch.zeros((NCLS_PAD, wcls.shape[1]), dtype=BF, device=x.device)
+        wp[:ncls] = _w2(wcls)
+        lg = ops.gemm(hb, wp, out_dtype=F32)
+        logits = ops.up_final_fwd(lg, B, H, W, ncls, scale)
+        ctx.save_for_backward(cols, c, mean, rstd, hb, wp, drop_mask)
+        ctx.head, ctx.geom, ctx.scale, ctx.training, ctx.plist = head, geom, scale, training, plist
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        cols, c, mean, rstd, hb, wp, drop_mask = ctx.saved_tensors
+        head, (B, H, W), training = ctx.head, ctx.geom, ctx.training
+        ncls = head[2][0].weight.shape[0]
+        gd = {}
+        dlg = ops.up_final_bwd(dlogits.contiguous(), NCLS_PAD, B, H, W, ncls, ctx.scale)
+        dhb = ops.gemm(dlg, wp.t().contiguous())
+        _put(gd, head[2][0].weight, ops.gemm_tn(dlg, hb)[:ncls])
+        dc, dg, dbt = _bn_bwd(dhb, c, mean, rstd, head[0][1], training, act=ACT_RELU6, dx_dtype=BF, chan_scale=drop_mask, rpi=H * W)
+        _put(gd, head[0][1].weight, dg); _put(gd, head[0][1].bias, dbt)
+        dx, dW3 = _conv3_bwd(dc, cols, head[0][0].weight, B, H, W)
+        _put(gd, head[0][0].weight, dW3)
+        return (ops.cast(dx, BF), None, None, None, None, None) + _grads(ctx.plist, gd)
+
+
+# ---------------------------------------------------------------------------------------------- channels-last <-> NCHW glue
+def to_rows(x_nchw, dtype=None):
+    """(B,C,H,W) -> contiguous [B*H*W, C] (layout change only)."""
+    B, C, H, W = x_nchw.shape
+    t = x_nchw.permute(0, 2, 3, 1).reshape(B * H * W, C)
+    return t.contiguous() if dtype is None else t.to(dtype).contiguous()
+
+
+def to_nchw(rows, B, H, W):
+    return rows.view(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+def layer_norm_nhwc(x, weight, bias, eps):
+    """LayerNorm over the last dim of a channels-last tensor (forward only; LayerNorm2d interface)."""
+    shp = x.shape
+    y, _, _ = ops.layernorm_fwd(x.reshape(-1, shp[-1]).contiguous().float(), weight, bias, eps, out_dtype=F32, want_stats=False)
+    return y.view(shp)

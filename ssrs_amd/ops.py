@@ -324,3 +324,267 @@ def transpose_pad(x, mult=64):
 def gemm_tn(dy, x):
     """dW[n,k] = sum_m dy[m,n] x[m,k]  (fp32 [N,K]); both bf16 row-major with M leading."""
     return gemm(transpose_pad(dy), transpose_pad(x), out_dtype=torch.float32)
+
+
+# ------------------------------------------------------------------------------------------ FPN / fusion / decoder
+# All maps are channels-last [rows, C]; see csrc/decoder.hip.
+ACT_NONE, ACT_RELU6, ACT_GELU = 0, 1, 2
+
+
+def _dt(t):
+    return _DT[t.dtype]
+
+
+def colsum(x, G, P, want_sq=False):
+    """x [G*P, C] -> (sum [G,C], sumsq [G,C] | None), fp32."""
+    _chk(x)
+    C = x.shape[-1]
+    assert x.is_contiguous() and x.numel() == G * P * C
+    s = torch.zeros((2 if want_sq else 1, G, C), dtype=torch.float32, device=x.device)
+    call("mfnet_colsum", x.data_ptr(), _dt(x), s[0].data_ptr(), s[1].data_ptr() if want_sq else None, G, P, C, _stream(x))
+    return s[0], (s[1] if want_sq else None)
+
+
+def coldot(a, b, G, P):
+    _chk(a, b)
+    C = a.shape[-1]
+    assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel() == G * P * C
+    out = torch.zeros((G, C), dtype=torch.float32, device=a.device)
+    call("mfnet_coldot", a.data_ptr(), _dt(a), b.data_ptr(), _dt(b), out.data_ptr(), G, P, C, _stream(a))
+    return out
+
+
+def bn_forward(x, gamma, beta, run_mean, run_var, nbt, training, eps=1e-5, momentum=0.1, act=ACT_NONE, chan_scale=None,
+               rows_per_image=0, out_dtype=torch.float32, out2_dtype=None):
+    """BatchNorm2d on a channels-last [rows, C] map. -> (y, y2 | None, mean, rstd)."""
+    _chk(x, gamma, beta)
+    rows, C = x.shape
+    assert x.is_contiguous()
+    st = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    if training:
+        s, sq = colsum(x, 1, rows, want_sq=True)
+        call("mfnet_bn_finalize", s.data_ptr(), sq.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), _p(run_mean), _p(run_var),
+             _p(nbt), C, rows, float(eps), float(momentum), 1, _stream(x))
+    else:
+        call("mfnet_bn_finalize", None, None, st[0].data_ptr(), st[1].data_ptr(), run_mean.data_ptr(), run_var.data_ptr(), None,
+             C, rows, float(eps), float(momentum), 0, _stream(x))
+    y = torch.empty((rows, C), dtype=out_dtype, device=x.device)
+    y2 = torch.empty((rows, C), dtype=out2_dtype, device=x.device) if out2_dtype is not None else None
+    call("mfnet_bn_apply", x.data_ptr(), _dt(x), st[0].data_ptr(), st[1].data_ptr(), gamma.data_ptr(), beta.data_ptr(), act,
+         _p(chan_scale), rows_per_image, y.data_ptr(), _dt(y), _p(y2), _dt(y2) if y2 is not None else 0, rows, C, _stream(x))
+    return y, y2, st[0], st[1]
+
+
+def bn_backward(dy, x, mean, rstd, gamma, beta, training, act=ACT_NONE, chan_scale=None, rows_per_image=0, dx_dtype=torch.float32):
+    """-> (dx, dgamma, dbeta)."""
+    _chk(dy, x)
+    rows, C = x.shape
+    assert dy.is_contiguous() and x.is_contiguous() and dy.shape == x.shape
+    sums = torch.zeros((2, C), dtype=torch.float32, device=x.device)
+    call("mfnet_bn_bwd_reduce", dy.data_ptr(), _dt(dy), x.data_ptr(), _dt(x), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+         beta.data_ptr(), act, _p(chan_scale), rows_per_image, sums[0].data_ptr(), sums[1].data_ptr(), rows, C, _stream(x))
+    dx = torch.empty((rows, C), dtype=dx_dtype, device=x.device)
+    call("mfnet_bn_bwd_apply", dy.data_ptr(), _dt(dy), x.data_ptr(), _dt(x), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+         beta.data_ptr(), act, _p(chan_scale), rows_per_image, sums[0].data_ptr(), sums[1].data_ptr(), 1 if training else 0,
+         dx.data_ptr(), _dt(dx), rows, C, _stream(x))
+    return dx, sums[1], sums[0]
+
+
+def act(x, kind, out_dtype=None):
+    _chk(x)
+    assert x.is_contiguous()
+    y = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
+    call("mfnet_act", x.data_ptr(), _dt(x), y.data_ptr(), _dt(y), kind, x.numel(), _stream(x))
+    return y
+
+
+def act_bwd(dy, ref, kind, out_dtype=torch.bfloat16):
+    _chk(dy, ref)
+    assert dy.is_contiguous() and ref.is_contiguous() and dy.shape == ref.shape
+    dx = torch.empty(dy.shape, dtype=out_dtype, device=dy.device)
+    call("mfnet_act_bwd", dy.data_ptr(), _dt(dy), ref.data_ptr(), _dt(ref), dx.data_ptr(), _dt(dx), kind, dy.numel(), _stream(dy))
+    return dx
+
+
+def dwconv_fwd(x, w, bias, B, H, W, k, ext):
+    _chk(x, w, bias)
+    C = x.shape[-1]
+    assert x.is_contiguous() and x.dtype == torch.float32 and w.is_contiguous() and w.numel() == C * k * k
+    y = torch.empty_like(x)
+    call("mfnet_dwconv_fwd", x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), B, H, W, C, k, 1 if ext else 0, _stream(x))
+    return y
+
+
+def dwconv_bwd(dy, x, w, B, H, W, k, ext, want_bias=False):
+    """-> (dx fp32, dw like w, dbias | None)."""
+    _chk(dy, x, w)
+    C = x.shape[-1]
+    assert dy.is_contiguous() and x.is_contiguous() and x.dtype == torch.float32
+    dx = torch.empty_like(x)
+    call("mfnet_dwconv_bwd_data", dy.data_ptr(), _dt(dy), w.data_ptr(), dx.data_ptr(), B, H, W, C, k, 1 if ext else 0, _stream(x))
+    dw = torch.zeros(w.shape, dtype=torch.float32, device=x.device)
+    db = torch.zeros(C, dtype=torch.float32, device=x.device) if want_bias else None
+    call("mfnet_dwconv_bwd_weight", dy.data_ptr(), _dt(dy), x.data_ptr(), dw.data_ptr(), _p(db), B, H, W, C, k, 1 if ext else 0, _stream(x))
+    return dx, dw, db
+
+
+def gla_attn_fwd(qkv, table, B, H, W, heads, scale):
+    _chk(qkv, table)
+    assert qkv.is_contiguous() and qkv.dtype == torch.bfloat16 and table.is_contiguous() and table.dtype == torch.float32
+    out = torch.empty((qkv.shape[0], heads * 8), dtype=torch.float32, device=qkv.device)
+    call("mfnet_gla_attn_fwd", qkv.data_ptr(), table.data_ptr(), out.data_ptr(), B, H, W, heads, qkv.shape[1] // (3 * heads), 8, float(scale), _stream(qkv))
+    return out
+
+
+def gla_attn_bwd(qkv, table, dout, B, H, W, heads, scale):
+    _chk(qkv, table, dout)
+    assert dout.is_contiguous() and dout.dtype == torch.float32
+    dqkv = torch.empty_like(qkv)
+    dtable = torch.zeros_like(table)
+    call("mfnet_gla_attn_bwd", qkv.data_ptr(), table.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), dtable.data_ptr(), B, H, W, heads,
+         qkv.shape[1] // (3 * heads), 8, float(scale), _stream(qkv))
+    return dqkv, dtable
+
+
+def gla_pool_fwd(o, l1, l2, B, H, W):
+    _chk(o, l1, l2)
+    out = torch.empty_like(o)
+    call("mfnet_gla_pool_fwd", o.data_ptr(), l1.data_ptr(), l2.data_ptr(), out.data_ptr(), B, H, W, o.shape[-1], _stream(o))
+    return out
+
+
+def gla_pool_bwd(ds, B, H, W):
+    _chk(ds)
+    assert ds.is_contiguous() and ds.dtype == torch.float32
+    d_o = torch.empty_like(ds)
+    call("mfnet_gla_pool_bwd", ds.data_ptr(), d_o.data_ptr(), B, H, W, ds.shape[-1], _stream(ds))
+    return d_o
+
+
+def upfuse_fwd(x, skip, perm, w, eps, B, H, W, out_dtype=torch.bfloat16):
+    """x [B*(H/2)*(W/2), C] fp32, skip [B*H*W, C] (row order `perm`) -> [B*H*W, C]."""
+    _chk(x, skip, w)
+    C = x.shape[-1]
+    assert x.is_contiguous() and x.dtype == torch.float32 and skip.is_contiguous() and skip.shape == (B * H * W, C)
+    out = torch.empty((B * H * W, C), dtype=out_dtype, device=x.device)
+    call("mfnet_upfuse_fwd", x.data_ptr(), skip.data_ptr(), _dt(skip), perm, w.data_ptr(), float(eps), out.data_ptr(), _dt(out), B, H, W, C, _stream(x))
+    return out
+
+
+def upfuse_bwd(df, x, skip, perm, w, eps, B, H, W, dskip_dtype=torch.bfloat16):
+    """-> (dx fp32, dskip, dw [2])."""
+    _chk(df, x, skip, w)
+    C = x.shape[-1]
+    assert df.is_contiguous() and df.dtype == torch.float32
+    dx = torch.empty_like(x)
+    dskip = torch.empty(skip.shape, dtype=dskip_dtype, device=x.device)
+    dw = torch.zeros(2, dtype=torch.float32, device=x.device)
+    sums = torch.empty(2, dtype=torch.float32, device=x.device)
+    call("mfnet_upfuse_bwd", df.data_ptr(), x.data_ptr(), skip.data_ptr(), _dt(skip), perm, w.data_ptr(), float(eps), dx.data_ptr(),
+         dskip.data_ptr(), _dt(dskip), dw.data_ptr(), sums.data_ptr(), B, H, W, C, _stream(x))
+    return dx, dskip, dw
+
+
+def up_final_fwd(x, B, h, w, ncls, s):
+    _chk(x)
+    assert x.is_contiguous() and x.dtype == torch.float32
+    out = torch.empty((B, ncls, h * s, w * s), dtype=torch.float32, device=x.device)
+    call("mfnet_up_final_fwd", x.data_ptr(), x.shape[-1], out.data_ptr(), B, h, w, ncls, s, _stream(x))
+    return out
+
+
+def up_final_bwd(dlogits, ldx, B, h, w, ncls, s):
+    _chk(dlogits)
+    assert dlogits.is_contiguous() and dlogits.dtype == torch.float32
+    dx = torch.empty((B * h * w, ldx), dtype=torch.bfloat16, device=dlogits.device)
+    call("mfnet_up_final_bwd", dlogits.data_ptr(), dx.data_ptr(), ldx, B, h, w, ncls, s, _stream(dlogits))
+    return dx
+
+
+def maxpool2_fwd(x, B, H, W):
+    _chk(x)
+    C = x.shape[-1]
+    assert x.is_contiguous() and x.dtype == torch.float32
+    y = torch.empty((B * (H // 2) * (W // 2), C), dtype=torch.float32, device=x.device)
+    arg = torch.empty((B * (H // 2) * (W // 2), C), dtype=torch.uint8, device=x.device)
+    call("mfnet_maxpool2_fwd", x.data_ptr(), y.data_ptr(), arg.data_ptr(), B, H, W, C, _stream(x))
+    return y, arg
+
+
+def maxpool2_bwd(dy, arg, dx, B, H, W, accumulate):
+    _chk(dy, arg, dx)
+    assert dy.is_contiguous() and dx.is_contiguous() and dx.dtype == torch.float32
+    call("mfnet_maxpool2_bwd", dy.data_ptr(), _dt(dy), arg.data_ptr(), dx.data_ptr(), B, H, W, dx.shape[-1], 1 if accumulate else 0, _stream(dx))
+    return dx
+
+
+def se_gate_fwd(pooled_sum, P, W1, b1, W2, b2, relu6):
+    _chk(pooled_sum, W1, W2)
+    B, C = pooled_sum.shape
+    Cr = W1.shape[0]
+    z = torch.empty((B, Cr), dtype=torch.float32, device=W1.device)
+    g = torch.empty((B, C), dtype=torch.float32, device=W1.device)
+    call("mfnet_se_gate_fwd", pooled_sum.data_ptr(), P, W1.data_ptr(), _p(b1), W2.data_ptr(), _p(b2), 1 if relu6 else 0, z.data_ptr(),
+         g.data_ptr(), B, C, Cr, _stream(W1))
+    return z, g
+
+
+def se_gate_bwd(dg, pooled_sum, P, W1, W2, relu6, z, g, has_bias):
+    """-> (dpool [B,C] (already / P), dW1, db1|None, dW2, db2|None)."""
+    B, C = pooled_sum.shape
+    Cr = W1.shape[0]
+    dev = W1.device
+    dpool = torch.empty((B, C), dtype=torch.float32, device=dev)
+    dW1 = torch.zeros(W1.shape, dtype=torch.float32, device=dev)
+    dW2 = torch.zeros(W2.shape, dtype=torch.float32, device=dev)
+    db1 = torch.zeros(Cr, dtype=torch.float32, device=dev) if has_bias else None
+    db2 = torch.zeros(C, dtype=torch.float32, device=dev) if has_bias else None
+    call("mfnet_se_gate_bwd", dg.data_ptr(), pooled_sum.data_ptr(), P, W1.data_ptr(), W2.data_ptr(), 1 if relu6 else 0, z.data_ptr(),
+         g.data_ptr(), dpool.data_ptr(), dW1.data_ptr(), _p(db1), dW2.data_ptr(), _p(db2), B, C, Cr, _stream(W1))
+    return dpool, dW1, db1, dW2, db2
+
+
+def se_scale_sum(rx, ry, gx, gy, B, P, out_dtype=torch.bfloat16):
+    _chk(rx, ry, gx, gy)
+    C = rx.shape[-1]
+    out = torch.empty((B * P, C), dtype=out_dtype, device=rx.device)
+    call("mfnet_se_scale_sum", rx.data_ptr(), _dt(rx), ry.data_ptr(), _dt(ry), gx.data_ptr(), gy.data_ptr(), out.data_ptr(), _dt(out), B, P, C, _stream(rx))
+    return out
+
+
+def se_bwd_apply(dres, gx, gy, dpx, dpy, B, P, dtype_x=None, dtype_y=None, out_x=None, out_y=None):
+    _chk(dres)
+    C = dres.shape[-1]
+    assert dres.is_contiguous()
+    drx = out_x if out_x is not None else torch.empty((B * P, C), dtype=dtype_x, device=dres.device)
+    dry = out_y if out_y is not None else torch.empty((B * P, C), dtype=dtype_y, device=dres.device)
+    assert drx.is_contiguous() and dry.is_contiguous()
+    call("mfnet_se_bwd_apply", dres.data_ptr(), _dt(dres), gx.data_ptr(), gy.data_ptr(), dpx.data_ptr(), dpy.data_ptr(), drx.data_ptr(),
+         _dt(drx), dry.data_ptr(), _dt(dry), B, P, C, _stream(dres))
+    return drx, dry
+
+
+def frh_gate_fwd(xf, dwo, gate, B, P):
+    _chk(xf, dwo, gate)
+    pc = torch.empty_like(xf)
+    call("mfnet_frh_gate_fwd", xf.data_ptr(), dwo.data_ptr(), gate.data_ptr(), pc.data_ptr(), B, P, xf.shape[-1], _stream(xf))
+    return pc
+
+
+def frh_gate_bwd(dpc, xf, dwo, gate, dpool, B, P):
+    _chk(dpc, xf, dwo, gate, dpool)
+    assert dpc.is_contiguous() and dpc.dtype == torch.float32
+    dxf = torch.empty_like(xf)
+    ddwo = torch.empty_like(xf)
+    call("mfnet_frh_gate_bwd", dpc.data_ptr(), xf.data_ptr(), dwo.data_ptr(), gate.data_ptr(), _p(dpool), dxf.data_ptr(), ddwo.data_ptr(),
+         B, P, xf.shape[-1], _stream(xf))
+    return dxf, ddwo
+
+
+def add3(a, b, c=None, out_dtype=torch.float32, out=None):
+    _chk(a, b, c)
+    assert a.is_contiguous() and b.is_contiguous() and (c is None or c.is_contiguous())
+    if out is None:
+        out = torch.empty(a.shape, dtype=out_dtype, device=a.device)
+    call("mfnet_add3", a.data_ptr(), _dt(a), b.data_ptr(), _dt(b), _p(c), _dt(c) if c is not None else 0, out.data_ptr(), _dt(out), a.numel(), _stream(a))
+    return out

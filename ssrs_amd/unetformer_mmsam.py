@@ -6,9 +6,9 @@ Same attribute names (.sam, .image_encoder, .fpn{1..4}{x,y}, .fusion{1..4}, .dec
 parameter names / state-dict layout (1088 keys for ViT-B MMLoRA, encoder registered under two names)
 and the same freeze rule. The multimodal SAM encoder runs on the gfx950 kernels (ssrs_amd/vit.py).
 
-ROUND-1 NOTE: the FPN / SE-fusion / UNetFormer decoder below (about 3 % of the forward FLOPs,
-SURVEY.md section 8d) still execute as ROCm PyTorch ops on the GPU; they are being replaced by the
-HBM-bound kernels of csrc/decoder.hip row by row (DESIGN.md "status").
+The classes below are parameter containers with the reference's names; their arithmetic lives in
+ssrs_amd/decoder_ops.py (one autograd.Function per module, channels-last, csrc/decoder.hip + the bf16
+GEMM). No torch arithmetic op is on the forward / backward path.
 """
 from __future__ import annotations
 
@@ -19,8 +19,14 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import decoder_ops as D
 from .medsam import cfg
 from .sam import sam_model_registry
+
+
+def _fused_only(name):
+    raise NotImplementedError(f"{name} has no standalone forward in the HIP path: it is computed inside the fused "
+                              "Block / FpnFusion functions of ssrs_amd/decoder_ops.py")
 
 
 class Norm2d(nn.Module):
@@ -31,7 +37,7 @@ class Norm2d(nn.Module):
         self.ln = nn.LayerNorm(embed_dim, eps=1e-6)
 
     def forward(self, x):
-        return self.ln(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2).contiguous()
+        return D.layer_norm_nhwc(x.permute(0, 2, 3, 1).contiguous(), self.ln.weight, self.ln.bias, self.ln.eps).permute(0, 3, 1, 2).contiguous()
 
 
 def _same_pad(k, stride=1, dilation=1):
@@ -70,7 +76,7 @@ class Mlp(nn.Module):
         self.fc2 = nn.Conv2d(hidden, dim, 1, 1, 0, bias=True)
 
     def forward(self, x):
-        return self.fc2(self.act(self.fc1(x)))
+        _fused_only("Mlp")
 
 
 class GlobalLocalAttention(nn.Module):
@@ -97,27 +103,7 @@ class GlobalLocalAttention(nn.Module):
             nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
 
     def forward(self, x):
-        B, C, H, W = x.shape
-        ws, nh = self.ws, self.num_heads
-        local = self.local2(x) + self.local1(x)
-        if W % ws:
-            x = F.pad(x, (0, ws - W % ws), mode="reflect")
-        if H % ws:
-            x = F.pad(x, (0, 0, 0, ws - H % ws), mode="reflect")
-        Hp, Wp = x.shape[2:]
-        d, hh, ww = C // nh, Hp // ws, Wp // ws
-        qkv = self.qkv(x).view(B, 3, nh, d, hh, ws, ww, ws).permute(1, 0, 4, 6, 2, 5, 7, 3)
-        q, k, v = qkv.reshape(3, B * hh * ww, nh, ws * ws, d).unbind(0)
-        dots = (q @ k.transpose(-2, -1)) * self.scale
-        if self.relative_pos_embedding:
-            bias = self.relative_position_bias_table[self.relative_position_index.view(-1)]
-            dots = dots + bias.view(ws * ws, ws * ws, -1).permute(2, 0, 1).unsqueeze(0)
-        o = dots.softmax(dim=-1) @ v
-        o = o.view(B, hh, ww, nh, ws, ws, d).permute(0, 3, 6, 1, 4, 2, 5).reshape(B, C, Hp, Wp)[:, :, :H, :W]
-        out = F.avg_pool2d(F.pad(o, (0, 0, 0, 1), mode="reflect"), (ws, 1), 1, (ws // 2 - 1, 0)) + \
-            F.avg_pool2d(F.pad(o, (0, 1, 0, 0), mode="reflect"), (1, ws), 1, (0, ws // 2 - 1))
-        out = F.pad(out + local, (0, 1, 0, 1), mode="reflect")
-        return self.proj(out)[:, :, :H, :W]
+        _fused_only("GlobalLocalAttention")
 
 
 class Block(nn.Module):
@@ -128,9 +114,13 @@ class Block(nn.Module):
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
         self.norm2 = nn.BatchNorm2d(dim)
 
+    def forward_rows(self, x, geom):
+        """x fp32 [B*H*W, C] channels-last rows."""
+        return D.BlockFn.apply(x, self, geom, self.training, *D.block_params(self))
+
     def forward(self, x):
-        x = x + self.attn(self.norm1(x))
-        return x + self.mlp(self.norm2(x))
+        B, C, H, W = x.shape
+        return D.to_nchw(self.forward_rows(D.to_rows(x.float()), (B, H, W)), B, H, W)
 
 
 class _Fuse(nn.Module):
@@ -141,11 +131,16 @@ class _Fuse(nn.Module):
         self.eps = eps
         self.post_conv = ConvBNReLU(decode_channels, decode_channels, kernel_size=3)
 
-    def fuse(self, x, res):
-        x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
-        w = F.relu(self.weights)
-        fw = w / (torch.sum(w, dim=0) + self.eps)
-        return self.post_conv(fw[0] * self.pre_conv(res) + fw[1] * x)
+    _FN = None
+
+    def forward_rows(self, x, res, perm, geom):
+        """x fp32 [B*(H/2)*(W/2), C]; res bf16 [B*H*W, Cin] in row order `perm`; geom = (B, H, W)."""
+        return type(self)._FN.apply(x, res, self, perm, geom, self.training, *type(self)._PARAMS(self))
+
+    def forward(self, x, res):
+        B, _, H, W = res.shape
+        out = self.forward_rows(D.to_rows(x.float()), D.to_rows(res, torch.bfloat16), 0, (B, H, W))
+        return D.to_nchw(out.float(), B, H, W)
 
 
 class WF(_Fuse):
@@ -154,8 +149,7 @@ class WF(_Fuse):
     def __init__(self, in_channels=128, decode_channels=128, eps=1e-8):
         super().__init__(in_channels, decode_channels, eps)
 
-    def forward(self, x, res):
-        return self.fuse(x, res)
+    _FN, _PARAMS = D.WFFn, staticmethod(D.wf_params)
 
 
 class FeatureRefinementHead(_Fuse):
@@ -171,11 +165,7 @@ class FeatureRefinementHead(_Fuse):
         self.proj = SeparableConvBN(dc, dc, kernel_size=3)
         self.act = nn.ReLU6()
 
-    def forward(self, x, res):
-        x = self.fuse(x, res)
-        shortcut = self.shortcut(x)
-        x = self.pa(x) * x + self.ca(x) * x
-        return self.act(self.proj(x) + shortcut)
+    _FN, _PARAMS = D.FRHFn, staticmethod(D.frh_params)
 
 
 class SqueezeAndExcitation(nn.Module):
@@ -185,7 +175,7 @@ class SqueezeAndExcitation(nn.Module):
                                 nn.Conv2d(channel // reduction, channel, kernel_size=1), nn.Sigmoid())
 
     def forward(self, x):
-        return x * self.fc(F.adaptive_avg_pool2d(x, 1))
+        _fused_only("SqueezeAndExcitation")
 
 
 class SEFusion(nn.Module):
@@ -195,7 +185,7 @@ class SEFusion(nn.Module):
         self.se_depth = SqueezeAndExcitation(channels_in, activation=activation)
 
     def forward(self, rgb, depth):
-        return self.se_rgb(rgb) + self.se_depth(depth)
+        _fused_only("SEFusion")
 
 
 class Decoder(nn.Module):
@@ -214,13 +204,28 @@ class Decoder(nn.Module):
         self.segmentation_head = nn.Sequential(ConvBNReLU(dc, dc), nn.Dropout2d(p=dropout, inplace=True),
                                                Conv(dc, num_classes, kernel_size=1))
 
+    def forward_rows(self, res1, res2, res3, res4, B, S, h, w, perms=(2, 1)):
+        """res_i: bf16 channels-last rows of the 4S, 2S, S, S/2 pyramid levels (res1 / res2 in the
+        un-shuffled ConvTranspose order `perms`); returns logits (B, ncls, h, w) fp32."""
+        if S % 2 or h != 16 * S or w != 16 * S:
+            raise NotImplementedError("the HIP decoder handles square pyramids with logits = 16x the encoder grid")
+        tr = self.training
+        x = D.ConvBN1x1Fn.apply(res4, self.pre_conv, tr, *D.convbn_params(self.pre_conv))
+        x = self.b4.forward_rows(x, (B, S // 2, S // 2))
+        x = self.b3.forward_rows(self.p3.forward_rows(x, res3, 0, (B, S, S)), (B, S, S))
+        x = self.b2.forward_rows(self.p2.forward_rows(x, res2, perms[1], (B, 2 * S, 2 * S)), (B, 2 * S, 2 * S))
+        x = self.p1.forward_rows(x, res1, perms[0], (B, 4 * S, 4 * S))
+        drop = self.segmentation_head[1]
+        mask = None
+        if drop.training and drop.p > 0:
+            keep = 1.0 - drop.p
+            mask = torch.bernoulli(torch.full((B, x.shape[1]), keep, device=x.device)) / keep     # Dropout2d: per (image, channel)
+        return D.SegHeadFn.apply(x, self.segmentation_head, (B, 4 * S, 4 * S), 4, mask, tr, *D.seghead_params(self.segmentation_head))
+
     def forward(self, res1, res2, res3, res4, h, w):
-        x = self.b4(self.pre_conv(res4))
-        x = self.b3(self.p3(x, res3))
-        x = self.b2(self.p2(x, res2))
-        x = self.p1(x, res1)
-        x = self.segmentation_head(x)
-        return F.interpolate(x, size=(h, w), mode="bilinear", align_corners=False)
+        B, _, S, _ = res3.shape
+        r = [D.to_rows(t, torch.bfloat16) for t in (res1, res2, res3, res4)]
+        return self.forward_rows(r[0], r[1], r[2], r[3], B, S, h, w, perms=(0, 0))
 
 
 class UNetFormer(nn.Module):
@@ -272,13 +277,8 @@ class UNetFormer(nn.Module):
         h, w = x.shape[-2:]
         B = x.shape[0]
         deep = self.image_encoder.forward_stacked(x, y)             # [2B, H/16, W/16, 256] channels-last
-        deepx = deep[:B].permute(0, 3, 1, 2)
-        deepy = deep[B:].permute(0, 3, 1, 2)
-        res1 = self.fusion1(self.fpn1x(deepx), self.fpn1y(deepy))
-        res2 = self.fusion2(self.fpn2x(deepx), self.fpn2y(deepy))
-        res3 = self.fusion3(self.fpn3x(deepx), self.fpn3y(deepy))
-        res4 = self.fusion4(self.fpn4x(deepx), self.fpn4y(deepy))
-        return self.decoder(res1, res2, res3, res4, h, w)
+        res1, res2, res3, res4 = D.FpnFusionFn.apply(deep, self, self.training, *D.fpn_fusion_params(self))
+        return self.decoder.forward_rows(res1, res2, res3, res4, B, deep.shape[1], h, w)
 
 
 UNetFormer_MMSAM = UNetFormer
