@@ -145,16 +145,21 @@ def main():
             eng.step(rgb, dsm, tgt)
         torch.cuda.synchronize()
         tr, ops.GEMM_TRACE = ops.GEMM_TRACE, None
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in tr)
-        fl = sum(f for _, _, f in tr)
+        ms = sum(t[0].elapsed_time(t[1]) for t in tr)
+        fl = sum(t[2] for t in tr)
         achieved = fl / (ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(achieved, 2),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": None, "launches_per_step": len(tr) // a.steps,
                     "avg_launch_us": round(1e3 * ms / len(tr), 2), "gflop_per_launch": round(fl / len(tr) / 1e9, 3),
                     "gemm_ms_per_step": round(ms / a.steps, 3)}
-    elif world > 1 and not a.no_roofline:
-        pass
+        if os.environ.get("MFNET_GEMM_SHAPES"):          # developer aid: per-shape GEMM time on stderr
+            agg = {}
+            for e0, e1, f, shp in tr:
+                d = agg.setdefault(shp, [0, 0.0, f])
+                d[0] += 1; d[1] += e0.elapsed_time(e1)
+            for shp, (n, t, f) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+                print(f"gemm M,N,K={shp}: {n // a.steps}/step {1e3 * t / n:8.1f} us  {f / (1e9 * t / n):8.1f} TF/s  {t / a.steps:7.3f} ms/step", file=sys.stderr)
     if world > 1:
         dist.barrier()
 

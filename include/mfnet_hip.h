@@ -64,12 +64,14 @@ int mfnet_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, const void* 
  * broadcasts a [res_row_mod, N] table over the rows (abs-pos-embed add, image_encoder.py:126-135).
  * Replaces: qkv / proj (lora_block.py:169-196), MLPBlock (lora_block.py:104-108), Adapter fc1/fc2
  * (common/adapter.py:16-25), PatchEmbed as im2col GEMM (image_encoder.py:189-197), neck convs (:104-120),
- * and the transposed-weight dgrads of all of them. */
+ * and the transposed-weight dgrads of all of them. k_splits > 1 (weight gradients: tiny M x N, K = number of
+ * pixels): the K range is cut over gridDim.y and slice s stores its fp32 partial at out + s*M*ldc, i.e. `out` is
+ * a [k_splits][M][ldc] scratch that mfnet_reduce_splits sums (fp32 out, no bias / low-rank / act / residual). */
 int mfnet_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int64_t N, int64_t K,
                     const float* bias, const float* U, int64_t ldu, const float* V, int64_t v_group_stride,
                     int64_t rows_per_group, int n_groups, int R, float lr_scale, int act, const void* aux,
                     int64_t ldaux, void* out_pre, int64_t ldpre, const float* residual, int64_t ldres,
-                    int64_t res_row_mod, void* out, int out_dtype, int64_t ldc, hipStream_t stream);
+                    int64_t res_row_mod, void* out, int out_dtype, int64_t ldc, int k_splits, hipStream_t stream);
 
 /* ---- skinny products of the low-rank paths (layers.py:149-165,244-268 forward "x @ A^T" and the
  * wgrads of lora_A / lora_B). nt: out[m,j] = scale * sum_k X[m,k] Wt[j,k], X bf16 [M,K], Wt fp32 [R,K],
@@ -78,7 +80,10 @@ int mfnet_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int6
 int mfnet_skinny_nt(const void* X, int64_t ldx, const float* Wt, int64_t ldw, float* out, int64_t ldo,
                     int64_t M, int64_t K, int R, float scale, hipStream_t stream);
 int mfnet_skinny_tn(const void* Y, int64_t ldy, const float* U, int64_t ldu, float* out, int64_t M, int64_t C,
-                    int R, int transposed, float scale, hipStream_t stream);
+                    int R, int transposed, float scale, float* workspace, int64_t workspace_floats, hipStream_t stream);
+/* scratch floats that make mfnet_skinny_tn atomic-free and deterministic (two-stage row reduction); with a
+ * null workspace the row splits meet in float atomics on `out`. */
+int64_t mfnet_skinny_tn_workspace_floats(int64_t M, int64_t C, int R);
 
 /* ---- LoRA cross-modal mix (layers.py:159-160): a [M,r] fp32 = [x@Ax^T ; y@Ay^T] (RGB rows first) ->
  * U [M,2r]: RGB rows [wx*ax, (1-wx)*ay], DSM rows [(1-wy)*ax, wy*ay]; backward returns da and ADDS
@@ -118,6 +123,8 @@ int mfnet_im2col_patch(const float* rgb, const float* dsm, void* cols, int64_t B
 int mfnet_im2col3x3(const void* x, void* cols, int64_t G, int64_t H, int64_t W, int64_t C, hipStream_t stream);
 int mfnet_col2im3x3(const void* dcols, float* dx, int64_t G, int64_t H, int64_t W, int64_t C, hipStream_t stream);
 int mfnet_transpose_bf16(const void* x, int64_t ld, void* y, int64_t M, int64_t N, int64_t Mp, hipStream_t stream);
+/* out[i] (= | +=) scale * sum_s partial[s*n + i], n % 4 == 0: second stage of the split-K weight gradients. */
+int mfnet_reduce_splits(const float* partial, float* out, int64_t n, int splits, float scale, int accumulate, hipStream_t stream);
 
 /* ---- MMAdapter glue (adapter_fusionblock.py:104-108): out = h + w*ada_own + (1-w)*ada_other per modality
  * (rows [0,M/2) RGB, [M/2,M) DSM); backward gives d ada (bf16) and ADDS (d wx_Adapter, d wy_Adapter) into

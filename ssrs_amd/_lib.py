@@ -32,9 +32,9 @@ _SIGS = {
     "mfnet_layernorm_fwd": [P, I, I64, P, P, P, I, I64, P, P, I64, I64, F, P],
     "mfnet_layernorm_bwd": [P, I, I64, P, I, I64, P, P, P, P, P, P, I64, P, P, I64, I64, P],
     "mfnet_gemm_bf16": [P, I64, P, I64, I64, I64, I64, P, P, I64, P, I64, I64, I, I, F, I, P, I64, P, I64,
-                        P, I64, I64, P, I, I64, P],
+                        P, I64, I64, P, I, I64, I, P],
     "mfnet_skinny_nt": [P, I64, P, I64, P, I64, I64, I64, I, F, P],
-    "mfnet_skinny_tn": [P, I64, P, I64, P, I64, I64, I, I, F, P],
+    "mfnet_skinny_tn": [P, I64, P, I64, P, I64, I64, I, I, F, P, I64, P],
     "mfnet_cast": [P, I, P, I, I64, P],
     "mfnet_im2col_patch": [P, P, P, I64, I64, I64, I64, P],
     "mfnet_im2col3x3": [P, P, I64, I64, I64, I64, P],
@@ -57,6 +57,7 @@ _SIGS = {
     "mfnet_add_bf16": [P, P, P, I64, P],
     "mfnet_bias_grad": [P, I64, P, I64, I64, P],
     "mfnet_transpose_bf16": [P, I64, P, I64, I64, I64, P],
+    "mfnet_reduce_splits": [P, P, I64, I, F, I, P],
     # ---- FPN / SE-fusion / UNetFormer decoder (csrc/decoder.hip)
     "mfnet_colsum": [P, I, P, P, I64, I64, I64, P],
     "mfnet_coldot": [P, I, P, I, P, I64, I64, I64, P],
@@ -101,6 +102,8 @@ def lib():
         L.mfnet_last_error.argtypes = []
         L.mfnet_version.restype = c_int
         L.mfnet_version.argtypes = []
+        L.mfnet_skinny_tn_workspace_floats.restype = c_int64
+        L.mfnet_skinny_tn_workspace_floats.argtypes = [c_int64, c_int64, c_int]
         for name, sig in _SIGS.items():
             fn = getattr(L, name, None)
             if fn is None:
@@ -112,7 +115,7 @@ def lib():
 
 
 def exported_symbols():
-    return ["mfnet_version", "mfnet_last_error"] + list(_SIGS)
+    return ["mfnet_version", "mfnet_last_error", "mfnet_skinny_tn_workspace_floats"] + list(_SIGS)
 
 
 def call(name: str, *args):

@@ -6,7 +6,11 @@
 //  * attn_bwd_dq : one workgroup per 64-query tile (query on the lane, like the forward):
 //        S^T, P^T recomputed; dP^T = V.dO^T; dS^T = P^T*(dP^T - delta);
 //        dQ^T = scale * K^T.dS^T + tbl^T.dT^T, where dT[q][row] = sum of dS over the keys that used
-//        table row `row` for that query (LDS float adds).
+//        table row `row` for that query. A key uses rows (KH-1-kh)+qh and Lh+(KW-1-kw)+qw: the key part is
+//        independent of the query, so the sums over keys are one more MFMA product per tile,
+//        dG^T = G^T.dS^T with the 0/1 indicator G[key][j] (j < KH: KH-1-kh == j; else KW-1-kw == j-KH),
+//        and the query offset (qh, qw) is applied once at the end. (The first version used LDS float
+//        atomics here and spent 12 of 50 ms per training step in this kernel.)
 //  * attn_bwd_dkv: one workgroup per 64 REAL keys (key on the lane), loops over the window's queries:
 //        dV^T += dO^T.P, dK^T += scale * Q^T.dS  with P / dS accumulator tiles reused as B operands.
 #include "attn_common.h"
@@ -40,12 +44,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
   const int Nk = g.KH * g.KW;
   const int TLD = g.NT + 4;
 
-  unsigned char* K_lds = smem;                                        // [256][64] swizzled
-  unsigned char* V_lds = smem + ATT_KC * ATT_HD * 2;                  // [256][64] swizzled
+  unsigned char* K_lds = smem;                                        // [KC][64] swizzled
+  unsigned char* V_lds = smem + ATT_KC * ATT_HD * 2;                  // [KC][64] swizzled
   bf16_t* Kt_lds = (bf16_t*)(smem + 2 * ATT_KC * ATT_HD * 2);         // [64][ATT_VT_LD]
   int* kidx_lds = (int*)((unsigned char*)Kt_lds + ATT_HD * ATT_VT_LD * 2);
   float* T_lds = (float*)(kidx_lds + ATT_KC);                         // [64][NT+4]
-  float* dT_lds = T_lds + ATT_QT * TLD;                               // [64][NT+4]
+  bf16_t* Gt_lds = (bf16_t*)(T_lds + ATT_QT * TLD);                   // [16*nG][ATT_VT_LD] key -> table-row indicators
+  float* dT_lds = (float*)smem;                                       // [64][NT+4], aliases K/V after the key loop
+  const int nG = (g.KH + g.KW + 15) >> 4;
 
   const int64_t row_base = (int64_t)gi * T;
   const int64_t ld = 3 * (int64_t)g.D;
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
     lse = p.lse[((int64_t)gi * g.heads + head) * T + qp.tok];
     if (!qp.valid) { qf[0] = qf[1] = dof[0] = dof[1] = z; delta = 0.f; lse = 0.f; }
   }
-  // T^T = tbl . Q^T -> T_lds ; zero dT_lds
+  // T^T = tbl . Q^T -> T_lds
   float* Trow = T_lds + (wave * 16 + fr) * TLD;
   float* dTrow = dT_lds + (wave * 16 + fr) * TLD;
   for (int t = 0; t < g.NT / 16; ++t) {
@@ -83,12 +89,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(tp), qf[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(tp + 32), qf[1], acc, 0, 0, 0);
     *reinterpret_cast<float4*>(Trow + 16 * t + 4 * fq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    *reinterpret_cast<float4*>(dTrow + 16 * t + 4 * fq) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
-  f32x4_t dq[4];
+  f32x4_t dq[4], dgt[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) dq[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < 4; ++u) { dq[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dgt[u] = dq[u]; }
 
   for (int kc = 0; kc < Nk; kc += ATT_KC) {
     __syncthreads();
@@ -119,6 +124,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
       kt_[4 * ATT_VT_LD] = (bf16_t)(kv.z & 0xffff); kt_[5 * ATT_VT_LD] = (bf16_t)(kv.z >> 16);
       kt_[6 * ATT_VT_LD] = (bf16_t)(kv.w & 0xffff); kt_[7 * ATT_VT_LD] = (bf16_t)(kv.w >> 16);
       if (ch == 0) kidx_lds[kl] = (g.KH - 1 - kh) | ((g.Lh + g.KW - 1 - kw) << 16);
+      // indicator rows: thread (kl, ch) fills rows ch, ch+8, ... of column kl
+      const int jh = g.KH - 1 - kh, jw = g.KH + g.KW - 1 - kw;
+      const bool kin = kg < Nk;
+      for (int j = ch; j < 16 * nG; j += 8) Gt_lds[j * ATT_VT_LD + kl] = (kin && (j == jh || j == jw)) ? (bf16_t)0x3f80 : (bf16_t)0;
     }
     __syncthreads();
     const int kvalid = min(ATT_KC, Nk - kc);
@@ -145,12 +154,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
           const int ih = (pk & 0xffff) + qp.qh, iw = (pk >> 16) + qp.qw;
           const float v = s[t][r] * g.scale + Trow[ih] + Trow[iw];
           const float pr = (kl < kvalid && qp.valid) ? __expf(v - lse) : 0.f;
-          const float ds = pr * (dp[t][r] - delta);
-          atomicAdd(dTrow + ih, ds);     // LDS float add; 4 lane groups share a query row
-          atomicAdd(dTrow + iw, ds);
-          s[t][r] = ds * g.scale;
+          s[t][r] = pr * (dp[t][r] - delta);          // dS (unscaled)
         }
-      // dQ^T += K^T . dS^T   (key-permuted k-steps, as in the forward's P.V)
+      // dQ^T += scale * K^T . dS^T and dG^T += G^T . dS^T   (key-permuted k-steps, as in the forward's P.V)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         union { bf16x8_t v; unsigned int w[4]; } pf;
@@ -166,10 +172,37 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
           kf.h[1] = *reinterpret_cast<const u32x2_t*>(kp + 16);
           dq[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf.v, pf.v, dq[u], 0, 0, 0);
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (u < nG) {
+            const bf16_t* gp = Gt_lds + (16 * u + fr) * ATT_VT_LD + kt * 64 + 32 * s2 + 4 * fq;
+            union { bf16x8_t v; u32x2_t h[2]; } gf;
+            gf.h[0] = *reinterpret_cast<const u32x2_t*>(gp);
+            gf.h[1] = *reinterpret_cast<const u32x2_t*>(gp + 16);
+            dgt[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf.v, pf.v, dgt[u], 0, 0, 0);
+          }
+        }
       }
     }
   }
-  __syncthreads();   // all LDS adds into dT complete
+  __syncthreads();   // K / V images dead: their LDS becomes dT
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { dq[u][0] *= g.scale; dq[u][1] *= g.scale; dq[u][2] *= g.scale; dq[u][3] *= g.scale; }
+  for (int t = 0; t < g.NT / 16; ++t) *reinterpret_cast<float4*>(dTrow + 16 * t + 4 * fq) = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  // dT[q][j + qh] = dG[q][j] (j < KH) ; dT[q][Lh + j' + qw] = dG[q][KH + j'] : one lane per (q, j), plain stores
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (u < nG) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * u + 4 * fq + r;
+        if (j < g.KH) dTrow[j + qp.qh] = dgt[u][r];
+        else if (j < g.KH + g.KW) dTrow[g.Lh + (j - g.KH) + qp.qw] = dgt[u][r];
+      }
+    }
+  }
+  __syncthreads();
   // dQ^T += tbl^T . dT^T
   for (int s3 = 0; s3 < g.NT / 32; ++s3) {
     const float4 d0 = *reinterpret_cast<const float4*>(dTrow + 32 * s3 + 8 * fq);
@@ -376,7 +409,9 @@ extern "C" int mfnet_attn_bwd(const void* qkv, const float* qkv_bias, const void
   dim3 grid((unsigned)ceil_div64(maxq, ATT_QT), (unsigned)heads, (unsigned)(G * p.g.nWh * p.g.nWw));
   MF_CHECK_ARG(grid.z <= 65535 && grid.y <= 65535, "attn_bwd: grid too large");
   const size_t TL = (size_t)ATT_QT * (p.g.NT + 4) * 4;
-  const size_t lds_dq = 2 * (size_t)ATT_KC * ATT_HD * 2 + (size_t)ATT_HD * ATT_VT_LD * 2 + ATT_KC * 4 + 2 * TL;
+  const size_t nGrows = 16 * (size_t)((p.g.KH + p.g.KW + 15) / 16);
+  MF_CHECK_ARG(nGrows <= 64 && TL <= 2 * (size_t)ATT_KC * ATT_HD * 2, "attn_bwd: key grid too large for the dT staging");
+  const size_t lds_dq = 2 * (size_t)ATT_KC * ATT_HD * 2 + (size_t)ATT_HD * ATT_VT_LD * 2 + ATT_KC * 4 + TL + nGrows * ATT_VT_LD * 2;
   const size_t lds_dkv = 2 * (size_t)ATT_QT * ATT_HD * 2 + 2 * (size_t)ATT_HD * QT_LD * 2 + 3 * ATT_QT * 4 + TL;
   // the two kernels write disjoint column ranges of dqkv (q | k,v); window mode leaves nothing unwritten
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), lds_dq, stream, p);

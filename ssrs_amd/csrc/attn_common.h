@@ -14,7 +14,7 @@
 #include "common.h"
 
 #define ATT_HD 64          // head dim (ViT-B / ViT-L)
-#define ATT_KC 256         // keys resident in LDS per chunk
+#define ATT_KC 128         // keys resident in LDS per chunk (small enough for 2-3 workgroups per CU)
 #define ATT_QT 64          // queries per workgroup (4 waves x 16)
 #define ATT_VT_LD (ATT_KC + 8)   // bf16 elements per row of the transposed [hd][key] images
 

@@ -38,6 +38,7 @@ struct GemmParams {
   const float* residual; int64_t ldres; int64_t res_row_mod;
   void* out; int out_dtype; int64_t ldc;
   int tiles_m, tiles_n;
+  int k_splits;                         // > 1: blockIdx.y owns a K range and stores its fp32 partial into slice blockIdx.y of out
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -115,12 +116,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  stage(0, 0);
-  for (int t = 0; t < nt; ++t) {
+  int t_begin = 0, t_end = nt;
+  if (p.k_splits > 1) {
+    t_begin = (int)((int64_t)nt * blockIdx.y / p.k_splits);
+    t_end = (int)((int64_t)nt * (blockIdx.y + 1) / p.k_splits);
+  }
+  if (t_begin < t_end) stage(t_begin, 0);
+  for (int t = t_begin; t < t_end; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
-    const unsigned char* base = lds + (t & 1) * ((BM + BN) * BK * 2);
+    if (t + 1 < t_end) stage(t + 1, (t + 1 - t_begin) & 1);
+    const unsigned char* base = lds + ((t - t_begin) & 1) * ((BM + BN) * BK * 2);
     const int nks = (half_tail && t == nt - 1) ? 1 : 2;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -149,6 +155,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
   for (int mi = 0; mi < 4; ++mi) {
     mrow[mi] = m0 + wm * 64 + mi * 16 + fr;
     mok[mi] = mrow[mi] < p.M;
+  }
+  if (p.k_splits > 1) {      // split-K partial: plain stores into slice blockIdx.y of out [k_splits][M][ldc]
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      if (!mok[mi]) continue;
+      float4* dst = reinterpret_cast<float4*>((float*)p.out + ((int64_t)blockIdx.y * p.M + mrow[mi]) * p.ldc + nb);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) dst[ni] = make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
+    }
+    return;
   }
   if (p.bias) {
 #pragma unroll
@@ -266,7 +282,7 @@ extern "C" int mfnet_gemm_bf16(const void* A, int64_t lda, const void* W, int64_
                                int64_t v_group_stride, int64_t rows_per_group, int n_groups, int R,
                                float lr_scale, int act, const void* aux, int64_t ldaux, void* out_pre,
                                int64_t ldpre, const float* residual, int64_t ldres, int64_t res_row_mod,
-                               void* out, int out_dtype, int64_t ldc, hipStream_t stream) {
+                               void* out, int out_dtype, int64_t ldc, int k_splits, hipStream_t stream) {
   MF_CHECK_ARG(A && W && out, "gemm_bf16: null operand");
   MF_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm_bf16: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   MF_CHECK_ARG(K % 32 == 0, "gemm_bf16: K=%lld must be a multiple of 32", (long long)K);
@@ -284,6 +300,9 @@ extern "C" int mfnet_gemm_bf16(const void* A, int64_t lda, const void* W, int64_
     MF_CHECK_ARG(n_groups >= 1 && (n_groups == 1 || rows_per_group > 0), "gemm_bf16: bad group args");
   }
   MF_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31), "gemm_bf16: shape too large");
+  MF_CHECK_ARG(k_splits >= 1 && k_splits <= 1024, "gemm_bf16: bad k_splits");
+  MF_CHECK_ARG(k_splits == 1 || (out_dtype == MFNET_F32 && !bias && !U && act == 0 && !out_pre && !residual),
+               "gemm_bf16: split-K supports only the plain fp32 accumulate-into-out epilogue");
   if (M == 0) return MFNET_OK;
   GemmParams p;
   p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw;
@@ -296,7 +315,8 @@ extern "C" int mfnet_gemm_bf16(const void* A, int64_t lda, const void* W, int64_
   p.tiles_m = (int)ceil_div64(M, BM); p.tiles_n = (int)ceil_div64(N, BN);
   const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
   MF_CHECK_ARG(nwg < (1ll << 31), "gemm_bf16: too many tiles");
-  hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)nwg), dim3(256), 0, stream, p);
+  p.k_splits = k_splits;
+  hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)nwg, (unsigned)k_splits), dim3(256), 0, stream, p);
   MF_LAUNCH_CHECK("gemm_bf16");
   return MFNET_OK;
 }

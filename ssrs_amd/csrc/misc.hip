@@ -220,3 +220,26 @@ extern "C" int mfnet_transpose_bf16(const void* x, int64_t ld, void* y, int64_t 
   MF_LAUNCH_CHECK("transpose_bf16");
   return MFNET_OK;
 }
+
+// ------------------------------------------------------------------------- split reduction
+// out[i] (= | +=) scale * sum_s partial[s*n + i]  : second stage of the split-K weight-gradient GEMMs
+__global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restrict__ partial, float* __restrict__ out, int64_t n4, int splits,
+                                                            float scale, int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < splits; ++s) {
+      const float4 v = reinterpret_cast<const float4*>(partial)[(int64_t)s * n4 + i];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    float4 o = make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale);
+    if (accumulate) { const float4 p = reinterpret_cast<float4*>(out)[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+    reinterpret_cast<float4*>(out)[i] = o;
+  }
+}
+extern "C" int mfnet_reduce_splits(const float* partial, float* out, int64_t n, int splits, float scale, int accumulate, hipStream_t stream) {
+  MF_CHECK_ARG(partial && out && n >= 0 && n % 4 == 0 && splits >= 1, "reduce_splits: bad args");
+  if (n == 0) return MFNET_OK;
+  hipLaunchKernelGGL(reduce_splits_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, partial, out, n / 4, splits, scale, accumulate);
+  MF_LAUNCH_CHECK("reduce_splits");
+  return MFNET_OK;
+}

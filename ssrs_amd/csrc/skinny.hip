@@ -69,7 +69,8 @@ template <int R>
 __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* __restrict__ Y, int64_t ldy,
                                                         const float* __restrict__ U, int64_t ldu,
                                                         float* __restrict__ out, int64_t M, int C,
-                                                        int64_t rows_per_block, int transposed, float scale) {
+                                                        int64_t rows_per_block, int transposed, float scale,
+                                                        float* __restrict__ partial) {
   __shared__ float red[64][8 * R + 1];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -117,6 +118,14 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* __restrict
     }
     __syncthreads();
   }
+  if (wave == 0 && active && partial) {      // two-stage mode: plain coalesced stores, reduced by skinny_tn_reduce_kernel
+    float4* dst = reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.y * C + c0) * R);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int j = 0; j < R; j += 4) dst[(e * R + j) >> 2] = make_float4(acc[e][j], acc[e][j + 1], acc[e][j + 2], acc[e][j + 3]);
+    return;
+  }
   if (wave == 0 && active) {
 #pragma unroll
     for (int e = 0; e < 8; ++e)
@@ -127,6 +136,36 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* __restrict
         else atomicAdd(out + (int64_t)(c0 + e) * R + j, v);
       }
   }
+}
+
+// out[c, j] (or out[j, c]) += scale * sum_s partial[s][c][j]
+__global__ __launch_bounds__(256) void skinny_tn_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int C, int R,
+                                                               int splits, int transposed, float scale) {
+  const int64_t n = (int64_t)C * R;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float a = 0.f;
+    for (int s = 0; s < splits; ++s) a += partial[(int64_t)s * n + i];
+    const int c = (int)(i / R), j = (int)(i - (int64_t)c * R);
+    float* o = transposed ? out + (int64_t)j * C + c : out + i;
+    *o += a * scale;
+  }
+}
+
+static void skinny_tn_geometry(int64_t M, int64_t C, int64_t* strips, int64_t* splits, int64_t* rpb) {
+  *strips = ceil_div64(C, 512);
+  int64_t sp = ceil_div64(256, *strips);              // aim for ~256 workgroups (one per CU)
+  int64_t r = ceil_div64(M, sp);
+  if (r < 64) r = 64;
+  r = ceil_div64(r, 4) * 4;
+  *rpb = r;
+  *splits = ceil_div64(M, r);
+}
+// floats of scratch that make mfnet_skinny_tn deterministic and atomic-free (two-stage reduction)
+extern "C" int64_t mfnet_skinny_tn_workspace_floats(int64_t M, int64_t C, int R) {
+  if (M <= 0 || C <= 0 || R <= 0) return 0;
+  int64_t strips, splits, rpb;
+  skinny_tn_geometry(M, C, &strips, &splits, &rpb);
+  return splits * C * R;
 }
 
 extern "C" int mfnet_skinny_nt(const void* X, int64_t ldx, const float* Wt, int64_t ldw, float* out,
@@ -144,24 +183,32 @@ extern "C" int mfnet_skinny_nt(const void* X, int64_t ldx, const float* Wt, int6
   return MFNET_OK;
 }
 
-// out must be zero-initialised (or hold the value to accumulate onto) by the caller.
+// out must be zero-initialised (or hold the value to accumulate onto) by the caller. With a workspace of
+// mfnet_skinny_tn_workspace_floats(M, C, R) floats the reduction over row splits is two-stage (plain stores +
+// one small reduce kernel: deterministic); without it the splits meet in float atomics on `out`.
 extern "C" int mfnet_skinny_tn(const void* Y, int64_t ldy, const float* U, int64_t ldu, float* out,
-                               int64_t M, int64_t C, int R, int transposed, float scale, hipStream_t stream) {
+                               int64_t M, int64_t C, int R, int transposed, float scale, float* workspace,
+                               int64_t workspace_floats, hipStream_t stream) {
   MF_CHECK_ARG(Y && U && out, "skinny_tn: null pointer");
   MF_CHECK_ARG(C > 0 && C % 8 == 0 && ldy % 8 == 0 && ldy >= C, "skinny_tn: bad C/ldy");
   MF_CHECK_ARG(R == 4 || R == 8 || R == 16, "skinny_tn: R=%d must be 4, 8 or 16", R);
   MF_CHECK_ARG(ldu >= R && ldu % 4 == 0, "skinny_tn: bad ldu");
   if (M <= 0) return MFNET_OK;
-  const int64_t strips = ceil_div64(C, 512);
-  int64_t splits = ceil_div64(256, strips);           // aim for ~256 workgroups (one per CU)
-  int64_t rpb = ceil_div64(M, splits);
-  if (rpb < 64) rpb = 64;
-  rpb = ceil_div64(rpb, 4) * 4;
-  splits = ceil_div64(M, rpb);
+  int64_t strips, splits, rpb;
+  skinny_tn_geometry(M, C, &strips, &splits, &rpb);
+  float* partial = nullptr;
+  if (workspace) {
+    MF_CHECK_ARG(workspace_floats >= splits * C * R, "skinny_tn: workspace too small (%lld < %lld floats)", (long long)workspace_floats, (long long)(splits * C * R));
+    partial = workspace;
+  }
   dim3 grid((unsigned)strips, (unsigned)splits), block(256);
-#define SKTN(RR) hipLaunchKernelGGL((skinny_tn_kernel<RR>), grid, block, 0, stream, (const bf16_t*)Y, ldy, U, ldu, out, M, (int)C, rpb, transposed, scale)
+#define SKTN(RR) hipLaunchKernelGGL((skinny_tn_kernel<RR>), grid, block, 0, stream, (const bf16_t*)Y, ldy, U, ldu, out, M, (int)C, rpb, transposed, scale, partial)
   if (R == 4) SKTN(4); else if (R == 8) SKTN(8); else SKTN(16);
 #undef SKTN
+  if (partial) {
+    int64_t g = ceil_div64(C * R, 256);
+    hipLaunchKernelGGL(skinny_tn_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, partial, out, (int)C, R, (int)splits, transposed, scale);
+  }
   MF_LAUNCH_CHECK("skinny_tn");
   return MFNET_OK;
 }

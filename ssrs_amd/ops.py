@@ -75,7 +75,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, want_f32=True, want_bf16=
 
 # ------------------------------------------------------------------------------------------ GEMM
 def gemm(a, w, *, bias=None, U=None, V=None, rows_per_group=0, n_groups=1, lr_scale=1.0, act=0, aux=None,
-         want_pre=False, residual=None, res_row_mod=0, out=None, out_dtype=torch.bfloat16):
+         want_pre=False, residual=None, res_row_mod=0, out=None, out_dtype=torch.bfloat16, k_splits=1):
     """out = a @ w^T (+bias +U V_g^T) -> act -> (+residual). a [M,K] bf16, w [N,K] bf16.
     V: [G,N,R] fp32. act: 0 none, 1 gelu (want_pre also returns the pre-activation), 2 multiply by
     gelu'(aux). Returns out or (out, pre)."""
@@ -84,7 +84,10 @@ def gemm(a, w, *, bias=None, U=None, V=None, rows_per_group=0, n_groups=1, lr_sc
     a2, M, K, lda = _rows2d(a)
     N, K2 = w.shape
     assert K2 == K and w.stride(1) == 1
-    if out is None:
+    if k_splits > 1:
+        assert out is None and out_dtype == torch.float32
+        out = torch.empty((k_splits, M, N), dtype=torch.float32, device=a.device)      # per-split partials
+    elif out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=a.device)
     assert out.stride(-1) == 1
     pre = torch.empty((M, N), dtype=torch.bfloat16, device=a.device) if want_pre else None
@@ -102,10 +105,10 @@ def gemm(a, w, *, bias=None, U=None, V=None, rows_per_group=0, n_groups=1, lr_sc
          _p(U), R if U is not None else 0, _p(V), vgs, rows_per_group, n_groups, R, float(lr_scale), act,
          _p(aux), aux.stride(-2) if aux is not None else 0, _p(pre), N if pre is not None else 0,
          _p(residual), residual.stride(-2) if residual is not None else 0, res_row_mod,
-         out.data_ptr(), _DT[out.dtype], out.stride(-2), _stream(a))
+         out.data_ptr(), _DT[out.dtype], out.stride(-2), k_splits, _stream(a))
     if GEMM_TRACE is not None:
         ev1.record(torch.cuda.current_stream(a.device))
-        GEMM_TRACE.append((ev0, ev1, 2.0 * M * N * K))
+        GEMM_TRACE.append((ev0, ev1, 2.0 * M * N * K, (M, N, K)))
     return (out, pre) if want_pre else out
 
 
@@ -131,8 +134,10 @@ def skinny_tn(y, u, transposed: bool, scale=1.0, out=None):
     if out is None:
         out = torch.zeros((R, C) if transposed else (C, R), dtype=torch.float32, device=y.device)
     assert out.is_contiguous()
+    nws = _lib.lib().mfnet_skinny_tn_workspace_floats(M, C, R)
+    ws = torch.empty(nws, dtype=torch.float32, device=y.device)
     call("mfnet_skinny_tn", y2.data_ptr(), ldy, u.data_ptr(), u.stride(0), out.data_ptr(), M, C, R,
-         1 if transposed else 0, float(scale), _stream(y))
+         1 if transposed else 0, float(scale), ws.data_ptr(), nws, _stream(y))
     return out
 
 
@@ -322,8 +327,18 @@ def transpose_pad(x, mult=64):
 
 
 def gemm_tn(dy, x):
-    """dW[n,k] = sum_m dy[m,n] x[m,k]  (fp32 [N,K]); both bf16 row-major with M leading."""
-    return gemm(transpose_pad(dy), transpose_pad(x), out_dtype=torch.float32)
+    """dW[n,k] = sum_m dy[m,n] x[m,k]  (fp32 [N,K]); both bf16 row-major with M leading. The reduction
+    runs over the rows (pixels / tokens), so it is cut into K-splits until ~512 workgroups exist."""
+    a, b = transpose_pad(dy), transpose_pad(x)
+    tiles = ((a.shape[0] + 127) // 128) * ((b.shape[0] + 127) // 128)
+    nt = a.shape[1] // 64
+    splits = max(1, min(nt // 4, 512 // tiles))
+    if splits == 1:
+        return gemm(a, b, out_dtype=torch.float32)
+    part = gemm(a, b, out_dtype=torch.float32, k_splits=splits)
+    out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
+    call("mfnet_reduce_splits", part.data_ptr(), out.data_ptr(), out.numel(), splits, 1.0, 0, _stream(part))
+    return out
 
 
 # ------------------------------------------------------------------------------------------ FPN / fusion / decoder

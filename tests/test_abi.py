@@ -31,7 +31,7 @@ def test_argument_errors_do_not_launch():
     from ssrs_amd import _lib
     L = _lib.lib()
     rc = L.mfnet_gemm_bf16(None, 0, None, 0, 4, 16, 64, None, None, 0, None, 0, 0, 1, 0, 1.0, 0, None, 0, None, 0,
-                           None, 0, 0, None, 1, 16, None)
+                           None, 0, 0, None, 1, 16, 1, None)
     assert rc == -1 and b"null" in L.mfnet_last_error()
     rc = L.mfnet_cast(1, 0, 1, 1, 7, None)
     assert rc == -1 and b"multiple of 8" in L.mfnet_last_error()

@@ -282,3 +282,14 @@ def test_tile_accumulate_argmax_minmax(ops):
     assert mm[0].item() == x.min().item() and mm[1].item() == x.max().item()
     y = ops.scale_shift(x, mm, 0)
     assert rel_err(y, (x - x.min()) / (x.max() - x.min())) < 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(65536, 64, 576), (16384, 256, 1024), (4100, 32, 64), (300, 192, 768)])
+def test_gemm_tn_split_k(ops, M, N, K):
+    """weight-gradient product dW = dY^T X through transpose + split-K GEMM + split reduction."""
+    dy = rnd(M, N, seed=1).to(torch.bfloat16)
+    x = rnd(M, K, seed=2).to(torch.bfloat16)
+    got = ops.gemm_tn(dy, x)
+    ref = dy.double().t() @ x.double()
+    assert got.shape == (N, K)
+    assert rel_err(got, ref) < 1e-4
