@@ -273,6 +273,25 @@ int mfnet_frh_gate_bwd(const float* dpc, const float* xf, const float* dwo, cons
 int mfnet_add3(const void* a, int a_dtype, const void* b, int b_dtype, const void* c, int c_dtype, void* out, int out_dtype,
                int64_t n, hipStream_t stream);
 
+/* ===================== sliding-window raster inference, pre / post steps (inference.py) =====================
+ * normalize_rgb_u8: out[c] = (in[c]*scale - mean3[c]) / std3[c] on a [3,H,W] uint8 raster (:464-484; mean3 /
+ * std3 are HOST arrays). extract_tiles: coords[t] = (row, col, valid_h, valid_w) int32; tiles shorter than the
+ * h x w window are filled with numpy 'reflect' padding (:726-737). tile_minmax_norm: per-tile DSM min-max in
+ * place, 0 when max == min (:547-555). tile_prob_accumulate: sum[row+y, col+x] += softmax(logits[t])[cls],
+ * cnt += 1 over each tile's valid extent (:562-566). blend_finish: prob = sum/cnt, mask = prob > threshold (:582). */
+int mfnet_normalize_rgb_u8(const unsigned char* in, float* out, int64_t H, int64_t W, float scale, const float* mean3,
+                           const float* std3, hipStream_t stream);
+int mfnet_extract_tiles(const float* rgb, const float* dsm, const int* coords, float* rgb_out, float* dsm_out, int64_t n,
+                        int64_t C, int64_t H, int64_t W, int64_t h, int64_t w, hipStream_t stream);
+int mfnet_tile_minmax_norm(float* tiles, int64_t n, int64_t per_tile, hipStream_t stream);
+int mfnet_tile_prob_accumulate(float* sum, float* cnt, const float* logits, const int* coords, int64_t n, int64_t C, int64_t H,
+                               int64_t W, int64_t h, int64_t w, int64_t cls, hipStream_t stream);
+int mfnet_blend_finish(const float* sum, const float* cnt, float* prob, unsigned char* mask, float threshold, int64_t n,
+                       hipStream_t stream);
+/* cm[gt*n + pred] += 1 for pixels with 0 <= gt < n: the confusion matrix behind utils2.metrics (utils2.py:168-216),
+ * pred uint8, gt int64, cm int64 [n,n] (zero first), n <= 32. */
+int mfnet_confusion(const unsigned char* pred, const int64_t* gt, int64_t* cm, int64_t n_classes, int64_t total, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

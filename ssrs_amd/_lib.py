@@ -87,6 +87,13 @@ _SIGS = {
     "mfnet_frh_gate_fwd": [P, P, P, P, I64, I64, I64, P],
     "mfnet_frh_gate_bwd": [P, P, P, P, P, P, P, I64, I64, I64, P],
     "mfnet_add3": [P, I, P, I, P, I, P, I, I64, P],
+    # ---- raster inference pre / post (csrc/infer.hip)
+    "mfnet_normalize_rgb_u8": [P, P, I64, I64, F, P, P, P],
+    "mfnet_extract_tiles": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, P],
+    "mfnet_tile_minmax_norm": [P, I64, I64, P],
+    "mfnet_tile_prob_accumulate": [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, P],
+    "mfnet_blend_finish": [P, P, P, P, F, I64, P],
+    "mfnet_confusion": [P, P, P, I64, I64, P],
 }
 
 

@@ -1,0 +1,156 @@
+// Sliding-window large-raster inference, on-device pre/post steps around the tile loop:
+//   * RGB normalisation (inference.py:464-484: /255 then ImageNet mean / std), tile extraction with the
+//     reflect padding of short edge tiles (inference.py:713-737), per-tile DSM min-max (inference.py:547-555)
+//   * softmax class probability of each tile accumulated into a raster sum + coverage count and blended
+//     (mean over the covering tiles), thresholded building mask (inference.py:562-566,582)
+// The evaluator-style merge (sum of raw logits, argmax; evaluator.py:169-176) lives in train.hip
+// (mfnet_tile_accumulate / mfnet_argmax_chw).
+#include "common.h"
+#include <float.h>
+
+static inline unsigned grid_for(int64_t work_items, int64_t cap = 16384) {
+  int64_t g = ceil_div64(work_items, 256);
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+// out[c,y,x] = (in[c,y,x] * scale - mean[c]) / std[c], in uint8
+__global__ __launch_bounds__(256) void normalize_u8_kernel(const unsigned char* __restrict__ in, float* __restrict__ out, int64_t hw, int C,
+                                                           float scale, float m0, float m1, float m2, float s0, float s1, float s2) {
+  const int64_t total = hw * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i / hw);
+    const float m = c == 0 ? m0 : (c == 1 ? m1 : m2), s = c == 0 ? s0 : (c == 1 ? s1 : s2);
+    out[i] = ((float)in[i] * scale - m) / s;
+  }
+}
+extern "C" int mfnet_normalize_rgb_u8(const unsigned char* in, float* out, int64_t H, int64_t W, float scale, const float* mean3,
+                                      const float* std3, hipStream_t stream) {
+  MF_CHECK_ARG(in && out && mean3 && std3 && H > 0 && W > 0, "normalize_rgb_u8: bad args (mean3 / std3 are HOST arrays of 3 floats)");
+  hipLaunchKernelGGL(normalize_u8_kernel, dim3(grid_for(3 * H * W)), dim3(256), 0, stream, in, out, H * W, 3, scale, mean3[0], mean3[1], mean3[2],
+                     std3[0], std3[1], std3[2]);
+  MF_LAUNCH_CHECK("normalize_rgb_u8");
+  return MFNET_OK;
+}
+
+// numpy 'reflect' index for a tile of valid length n padded to a longer window
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < n ? i : 2 * n - 2 - i; }
+// coords[t] = (row, col, valid_h, valid_w); rgb [C,H,W] fp32, dsm [H,W] fp32 -> rgb_out [n,C,h,w], dsm_out [n,h,w]
+__global__ __launch_bounds__(256) void extract_tiles_kernel(const float* __restrict__ rgb, const float* __restrict__ dsm, const int* __restrict__ coords,
+                                                            float* __restrict__ rgb_out, float* __restrict__ dsm_out, int64_t n, int C, int64_t H,
+                                                            int64_t W, int h, int w) {
+  const int64_t per = (int64_t)(C + 1) * h * w, total = n * per;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / per;
+    int64_t r = i - t * per;
+    const int c = (int)(r / ((int64_t)h * w));
+    r -= (int64_t)c * h * w;
+    const int y = (int)(r / w), x = (int)(r - (int64_t)y * w);
+    const int* cd = coords + 4 * t;
+    const int64_t sy = cd[0] + reflect_idx(y, cd[2]), sx = cd[1] + reflect_idx(x, cd[3]);
+    if (c < C) rgb_out[((t * C + c) * h + y) * (int64_t)w + x] = rgb[((int64_t)c * H + sy) * W + sx];
+    else dsm_out[(t * h + y) * (int64_t)w + x] = dsm[sy * W + sx];
+  }
+}
+extern "C" int mfnet_extract_tiles(const float* rgb, const float* dsm, const int* coords, float* rgb_out, float* dsm_out, int64_t n, int64_t C,
+                                   int64_t H, int64_t W, int64_t h, int64_t w, hipStream_t stream) {
+  MF_CHECK_ARG(rgb && dsm && coords && rgb_out && dsm_out && C > 0 && h > 0 && w > 0, "extract_tiles: bad args");
+  if (n <= 0) return MFNET_OK;
+  hipLaunchKernelGGL(extract_tiles_kernel, dim3(grid_for(n * (C + 1) * h * w)), dim3(256), 0, stream, rgb, dsm, coords, rgb_out, dsm_out, n, (int)C, H, W, (int)h, (int)w);
+  MF_LAUNCH_CHECK("extract_tiles");
+  return MFNET_OK;
+}
+
+// per-tile min-max normalisation in place: (x - min) / (max - min), 0 when max == min; one block per tile
+__global__ __launch_bounds__(256) void tile_minmax_norm_kernel(float* __restrict__ x, int64_t per) {
+  __shared__ float lo_s[4], hi_s[4];
+  float* p = x + (int64_t)blockIdx.x * per;
+  float lo = FLT_MAX, hi = -FLT_MAX;
+  for (int64_t i = threadIdx.x; i < per; i += 256) { const float v = p[i]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
+  hi = wave_max(hi); lo = -wave_max(-lo);
+  if ((threadIdx.x & 63) == 0) { lo_s[threadIdx.x >> 6] = lo; hi_s[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  lo = fminf(fminf(lo_s[0], lo_s[1]), fminf(lo_s[2], lo_s[3]));
+  hi = fmaxf(fmaxf(hi_s[0], hi_s[1]), fmaxf(hi_s[2], hi_s[3]));
+  const float rng = hi - lo;
+  for (int64_t i = threadIdx.x; i < per; i += 256) p[i] = rng > 0.f ? (p[i] - lo) / rng : 0.f;
+}
+extern "C" int mfnet_tile_minmax_norm(float* tiles, int64_t n, int64_t per_tile, hipStream_t stream) {
+  MF_CHECK_ARG(tiles && per_tile > 0 && n < (1ll << 31), "tile_minmax_norm: bad args");
+  if (n <= 0) return MFNET_OK;
+  hipLaunchKernelGGL(tile_minmax_norm_kernel, dim3((unsigned)n), dim3(256), 0, stream, tiles, per_tile);
+  MF_LAUNCH_CHECK("tile_minmax_norm");
+  return MFNET_OK;
+}
+
+// sum[row+y, col+x] += softmax(logits[t,:,y,x])[cls] ; cnt[...] += 1 over the valid extent of each tile
+__global__ __launch_bounds__(256) void tile_prob_accumulate_kernel(float* __restrict__ sum, float* __restrict__ cnt, const float* __restrict__ logits,
+                                                                   const int* __restrict__ coords, int64_t n, int C, int64_t W, int h, int w, int cls) {
+  const int64_t per = (int64_t)h * w, total = n * per;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / per;
+    const int64_t r = i - t * per;
+    const int y = (int)(r / w), x = (int)(r - (int64_t)y * w);
+    const int* cd = coords + 4 * t;
+    if (y >= cd[2] || x >= cd[3]) continue;
+    const float* lp = logits + t * C * per + r;
+    float mx = -FLT_MAX;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, lp[(int64_t)c * per]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += __expf(lp[(int64_t)c * per] - mx);
+    const float pr = __expf(lp[(int64_t)cls * per] - mx) / se;
+    const int64_t o = (int64_t)(cd[0] + y) * W + cd[1] + x;
+    atomicAdd(sum + o, pr);
+    atomicAdd(cnt + o, 1.f);
+  }
+}
+extern "C" int mfnet_tile_prob_accumulate(float* sum, float* cnt, const float* logits, const int* coords, int64_t n, int64_t C, int64_t H, int64_t W,
+                                          int64_t h, int64_t w, int64_t cls, hipStream_t stream) {
+  MF_CHECK_ARG(sum && cnt && logits && coords && C > 0 && cls >= 0 && cls < C && h > 0 && w > 0, "tile_prob_accumulate: bad args");
+  if (n <= 0) return MFNET_OK;
+  hipLaunchKernelGGL(tile_prob_accumulate_kernel, dim3(grid_for(n * h * w)), dim3(256), 0, stream, sum, cnt, logits, coords, n, (int)C, W, (int)h, (int)w, (int)cls);
+  MF_LAUNCH_CHECK("tile_prob_accumulate");
+  return MFNET_OK;
+}
+// prob = sum / cnt (0 where no tile covers the pixel) ; mask = prob > threshold
+__global__ __launch_bounds__(256) void blend_finish_kernel(const float* __restrict__ sum, const float* __restrict__ cnt, float* __restrict__ prob,
+                                                           unsigned char* __restrict__ mask, float thr, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float c = cnt[i];
+    const float p = c > 0.f ? sum[i] / c : 0.f;
+    if (prob) prob[i] = p;
+    if (mask) mask[i] = p > thr ? 1 : 0;
+  }
+}
+extern "C" int mfnet_blend_finish(const float* sum, const float* cnt, float* prob, unsigned char* mask, float threshold, int64_t n, hipStream_t stream) {
+  MF_CHECK_ARG(sum && cnt && (prob || mask) && n >= 0, "blend_finish: bad args");
+  if (n == 0) return MFNET_OK;
+  hipLaunchKernelGGL(blend_finish_kernel, dim3(grid_for(n)), dim3(256), 0, stream, sum, cnt, prob, mask, threshold, n);
+  MF_LAUNCH_CHECK("blend_finish");
+  return MFNET_OK;
+}
+
+// confusion matrix cm[gt*n + pred] += 1 over pixels with 0 <= gt < n (utils2.py:168-176: sklearn
+// confusion_matrix(gts, predictions, labels=range(n))); pred uint8, gt int64, cm int64 [n, n] (zero first)
+__global__ __launch_bounds__(256) void confusion_kernel(const unsigned char* __restrict__ pred, const int64_t* __restrict__ gt, unsigned long long* __restrict__ cm,
+                                                        int n, int64_t total) {
+  __shared__ unsigned int loc[32 * 32];
+  for (int i = threadIdx.x; i < n * n; i += 256) loc[i] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t g = gt[i];
+    const int p = pred[i];
+    if (g >= 0 && g < n && p < n) atomicAdd(&loc[(int)g * n + p], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n * n; i += 256)
+    if (loc[i]) atomicAdd(cm + i, (unsigned long long)loc[i]);
+}
+extern "C" int mfnet_confusion(const unsigned char* pred, const int64_t* gt, int64_t* cm, int64_t n_classes, int64_t total, hipStream_t stream) {
+  MF_CHECK_ARG(pred && gt && cm && n_classes > 0 && n_classes <= 32 && total >= 0, "confusion: bad args (n_classes <= 32)");
+  if (total == 0) return MFNET_OK;
+  hipLaunchKernelGGL(confusion_kernel, dim3(grid_for(total, 1024)), dim3(256), 0, stream, pred, gt, (unsigned long long*)cm, (int)n_classes, total);
+  MF_LAUNCH_CHECK("confusion");
+  return MFNET_OK;
+}

@@ -1,0 +1,264 @@
+"""Sliding-window large-raster prediction for MFNet with the tile loop, normalisation, overlap merge and
+arg-max on the device, and tiles sharded over the ranks of a torch.distributed group.
+
+Two reference call paths are covered (paths relative to /root/reference):
+  * `Evaluator._predict_image` (evaluator.py:113-176) with `utils2.sliding_window / grouper`
+    (utils2.py:134-165): windows at range(0, H, stride) with the tail clamped to H - win, DSM min-max over
+    the WHOLE raster, raw logits SUMMED over overlapping windows, arg-max  -> `SlidingWindowPredictor`.
+  * `BuildingInference` tile loop (inference.py:498-568, 687-744): stride = win - int(win*overlap), tail
+    tile shifted to the edge, short tiles reflect-padded, ImageNet-normalised RGB, PER-TILE DSM min-max,
+    softmax probability of class 1 -> `RasterInference`. The reference vectorises every tile on the CPU
+    and merges polygons (out of scope); here the per-tile probabilities are blended on the
+    device (mean over the covering tiles) into one raster + a thresholded mask that a vectoriser can take.
+
+Multi-GPU (one process per GPU): the window list is cut into `world` contiguous runs (row-major, so each
+rank works on a horizontal band of the raster and keeps an accumulator for that band only); rows that
+two neighbouring bands share are passed down a chain of point-to-point transfers (rank r -> r+1), then
+every rank arg-maxes the rows it owns and the uint8 masks are combined. No collective touches logits.
+"""
+from __future__ import annotations
+
+from itertools import islice
+from typing import Callable, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+# ---------------------------------------------------------------------------------------------- window grids (host)
+def sliding_window(top, step=10, window_size=(20, 20)):
+    """utils2.py:134-142: yields (x, y, w, h) with x the ROW offset; tail positions clamped to the edge."""
+    H, W = top.shape[:2] if hasattr(top, "shape") else top
+    for x in range(0, H, step):
+        if x + window_size[0] > H:
+            x = H - window_size[0]
+        for y in range(0, W, step):
+            if y + window_size[1] > W:
+                y = W - window_size[1]
+            yield x, y, window_size[0], window_size[1]
+
+
+def count_sliding_window(top, step=10, window_size=(20, 20)):
+    """utils2.py:145-155."""
+    return sum(1 for _ in sliding_window(top, step, window_size))
+
+
+def grouper(n, iterable):
+    """utils2.py:158-165: chunks of n items (the last one shorter)."""
+    it = iter(iterable)
+    while True:
+        chunk = tuple(islice(it, n))
+        if not chunk:
+            return
+        yield chunk
+
+
+def get_sliding_windows(height: int, width: int, window_size=(256, 256), overlap: int = 64):
+    """inference.py:498-533 (_get_sliding_windows): (y, x, y_end, x_end); `overlap` in pixels."""
+    wh, ww = window_size
+    sh, sw = wh - overlap, ww - overlap
+    out = []
+    for y in range(0, height, sh):
+        for x in range(0, width, sw):
+            ye, xe = min(y + wh, height), min(x + ww, width)
+            if (ye - y) >= wh // 2 and (xe - x) >= ww // 2:
+                yy, xx = y, x
+                if ye == height and ye - yy < wh:
+                    yy = max(0, height - wh)
+                if xe == width and xe - xx < ww:
+                    xx = max(0, width - ww)
+                out.append((yy, xx, ye, xe))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- band plan (host)
+def plan_bands(rows: Sequence[int], heights: Sequence[int], H: int, world: int):
+    """Cut a row-major window list (top rows `rows`, non-decreasing; tile heights `heights`) into `world`
+    contiguous runs. Returns one dict per rank: first/last window index (half-open), band rows [lo, hi)
+    covered by its windows, owned rows [own_lo, own_hi) (a partition of [0, H)). Rank r sends the rows
+    [own_hi, hi) of its accumulator to rank r+1 after having received from rank r-1."""
+    n = len(rows)
+    assert n > 0 and all(rows[i] <= rows[i + 1] for i in range(n - 1)), "window rows must be non-decreasing"
+    world = max(1, min(world, n))
+    cuts = [round(i * n / world) for i in range(world + 1)]
+    plan = []
+    for r in range(world):
+        a, b = cuts[r], cuts[r + 1]
+        lo = rows[a]
+        hi = max(rows[i] + heights[i] for i in range(a, b))
+        plan.append(dict(rank=r, first=a, last=b, lo=lo, hi=hi))
+    for r in range(world):
+        plan[r]["own_lo"] = 0 if r == 0 else plan[r]["lo"]
+        plan[r]["own_hi"] = H if r == world - 1 else plan[r + 1]["lo"]
+        plan[r]["lo"] = plan[r]["own_lo"] if r == 0 else plan[r]["lo"]
+        plan[r]["hi"] = max(plan[r]["hi"], plan[r]["own_hi"]) if r == world - 1 else plan[r]["hi"]
+    for r in range(world - 1):                  # forwarded rows must fit inside the next band
+        plan[r + 1]["hi"] = max(plan[r + 1]["hi"], plan[r]["hi"])
+    return plan
+
+
+def merge_bands(band: torch.Tensor, plan, rank: int, add_rows: Callable[[torch.Tensor, torch.Tensor], None], group=None):
+    """Chain exchange of the rows neighbouring bands share. band: [C, hi-lo, W] accumulator of `rank`.
+    add_rows(dst_rows_view_spec, src) adds a received [C, k, W] block onto the top k rows of the band."""
+    world = len(plan)
+    me = plan[rank]
+    if rank > 0:
+        prev = plan[rank - 1]
+        k = prev["hi"] - prev["own_hi"]
+        if k > 0:
+            buf = torch.empty((band.shape[0], k, band.shape[2]), dtype=band.dtype, device=band.device)
+            dist.recv(buf, src=rank - 1, group=group)
+            add_rows(band, buf)
+    if rank < world - 1:
+        k = me["hi"] - me["own_hi"]
+        if k > 0:
+            dist.send(band[:, me["own_hi"] - me["lo"]:me["hi"] - me["lo"], :].contiguous(), dst=rank + 1, group=group)
+
+
+def _dist_info(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def _device_add_rows(band, buf):
+    """band[:, :k, :] += buf through the tile-accumulate kernel (one 'tile' of k x W at the origin)."""
+    coords = torch.zeros((1, 2), dtype=torch.int32, device=band.device)
+    ops.tile_accumulate(band, buf[None].contiguous(), coords, atomic=False)
+
+
+# ---------------------------------------------------------------------------------------------- evaluator-style
+class SlidingWindowPredictor:
+    """On-device `Evaluator._predict_image` (evaluator.py:113-176)."""
+
+    def __init__(self, forward: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], n_classes: int,
+                 window_size=(256, 256), batch_size: int = 16, group=None):
+        self.forward, self.n_classes = forward, n_classes
+        self.window_size, self.batch_size, self.group = tuple(window_size), batch_size, group
+
+    @torch.no_grad()
+    def predict(self, img: torch.Tensor, dsm: torch.Tensor, stride: int, return_scores: bool = False):
+        """img [3,H,W] fp32 on the device (already scaled as in training), dsm [H,W] fp32 raw.
+        Returns the uint8 class map [H,W] (identical on every rank) and, if asked, this rank's summed
+        logits for the rows it owns (`(scores [C, rows, W], row_lo)`)."""
+        C, (h, w) = self.n_classes, self.window_size
+        _, H, W = img.shape
+        if W % 4 or w % 4:
+            raise ValueError("raster width and window width must be multiples of 4")
+        rank, world = _dist_info(self.group)
+        coords = [(x, y) for x, y, _, _ in sliding_window((H, W), stride, (h, w))]
+        plan = plan_bands([c[0] for c in coords], [h] * len(coords), H, world)
+        if rank >= len(plan):               # more ranks than windows
+            me = dict(first=0, last=0, lo=0, hi=0, own_lo=0, own_hi=0)
+        else:
+            me = plan[rank]
+        mm = ops.minmax(dsm.contiguous())                                   # whole-raster min / max (evaluator.py:100-111)
+        d = ops.scale_shift(dsm.contiguous(), mm, 0)
+        band = torch.zeros((C, max(1, me["hi"] - me["lo"]), W), dtype=torch.float32, device=img.device)
+        mine = coords[me["first"]:me["last"]]
+        for chunk in grouper(self.batch_size, mine):
+            c4 = torch.tensor([(r, c, h, w) for r, c in chunk], dtype=torch.int32, device=img.device)
+            rgb_t, dsm_t = ops.extract_tiles(img, d, c4, h, w)
+            logits = self.forward(rgb_t, dsm_t).float().contiguous()
+            c2 = (c4[:, :2] - torch.tensor([me["lo"], 0], dtype=torch.int32, device=img.device)).contiguous()
+            ops.tile_accumulate(band, logits, c2, atomic=True)              # pred[x:x+w, y:y+h] += out (evaluator.py:169-171)
+        if world > 1 and rank < len(plan):
+            merge_bands(band, plan, rank, _device_add_rows, self.group)
+        mask = torch.zeros((H, W), dtype=torch.uint8, device=img.device)
+        own = band[:, me["own_lo"] - me["lo"]:me["own_hi"] - me["lo"], :].contiguous()
+        if own.shape[1] > 0:
+            mask[me["own_lo"]:me["own_hi"]] = ops.argmax_chw(own)
+        if world > 1:
+            dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)   # owned row ranges are disjoint
+        return (mask, (own, me["own_lo"])) if return_scores else mask
+
+
+class Evaluator:
+    """evaluator.py:22-291 with in-memory rasters (file I/O is host code outside the hot path):
+    `_predict_image(net, img (H,W,3) float in [0,1], dsm (H,W), stride, batch_size, window_size)` returns
+    the numpy class map like the reference; `evaluate(model_wrapper, samples, stride)` returns mIoU over
+    the first 5 classes (utils2.py:168-216) from an on-device confusion matrix."""
+
+    def __init__(self, n_classes: int = 6, window_size=(256, 256), batch_size: int = 10):
+        self.n_classes, self.window_size, self.batch_size = n_classes, tuple(window_size), batch_size
+
+    def _predict_image(self, net, img, dsm, stride, batch_size=None, window_size=None, device="cuda"):
+        fwd = lambda a, b: net.forward(a, b, mode="Test") if hasattr(net, "forward") else net(a, b)      # noqa: E731
+        p = SlidingWindowPredictor(fwd, self.n_classes, window_size or self.window_size, batch_size or self.batch_size)
+        it = torch.as_tensor(np.ascontiguousarray(np.asarray(img, dtype=np.float32).transpose(2, 0, 1)), device=device)
+        dt = torch.as_tensor(np.asarray(dsm, dtype=np.float32), device=device)
+        return p.predict(it, dt, stride).cpu().numpy()
+
+    def evaluate(self, model_wrapper, samples: Iterable[Tuple[np.ndarray, np.ndarray, np.ndarray]], stride: int = 64, device="cuda"):
+        cm = torch.zeros((self.n_classes, self.n_classes), dtype=torch.int64, device=device)
+        model_wrapper.set_eval_mode()
+        for img, dsm, gt in samples:
+            p = SlidingWindowPredictor(lambda a, b: model_wrapper.forward(a, b, mode="Test"), self.n_classes, self.window_size, self.batch_size)
+            it = torch.as_tensor(np.ascontiguousarray(np.asarray(img, dtype=np.float32).transpose(2, 0, 1)), device=device)
+            mask = p.predict(it, torch.as_tensor(np.asarray(dsm, dtype=np.float32), device=device), stride)
+            cm += ops.confusion(mask.reshape(-1).contiguous(), torch.as_tensor(np.asarray(gt, dtype=np.int64), device=device).reshape(-1), self.n_classes)
+        return metrics_from_confusion(cm.cpu().numpy())["mIoU"]
+
+
+def metrics_from_confusion(cm: np.ndarray):
+    """utils2.py:177-216 (OA, per-class F1, kappa, mIoU over the first 5 classes) from a confusion matrix."""
+    cm = np.asarray(cm, dtype=np.float64)
+    total = cm.sum()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        oa = 100.0 * np.trace(cm) / total
+        f1 = 2.0 * np.diag(cm) / (cm.sum(1) + cm.sum(0))
+        pa = np.trace(cm) / total
+        pe = np.sum(cm.sum(0) * cm.sum(1)) / (total * total)
+        kappa = (pa - pe) / (1 - pe)
+        iou = np.diag(cm) / (cm.sum(1) + cm.sum(0) - np.diag(cm))
+    return dict(cm=cm, OA=oa, F1=f1, kappa=kappa, mIoU=float(np.nanmean(iou[:5])))
+
+
+# ---------------------------------------------------------------------------------------------- inference.py-style
+class RasterInference:
+    """Tile loop of `BuildingInference` (inference.py:498-568, 687-744) with an on-device overlap blend."""
+
+    def __init__(self, forward: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], window_size=(256, 256),
+                 overlap_ratio: float = 0.25, batch_size: int = 16, building_class: int = 1, threshold: float = 0.5, group=None):
+        self.forward, self.window_size = forward, tuple(window_size)
+        self.overlap = int(self.window_size[0] * overlap_ratio)                 # inference.py:139-141
+        self.batch_size, self.cls, self.threshold, self.group = batch_size, building_class, threshold, group
+
+    @torch.no_grad()
+    def predict(self, rgb: torch.Tensor, dem: torch.Tensor):
+        """rgb [3,H,W] uint8 (or fp32 already normalised), dem [H,W] fp32 raw, both on the device.
+        -> (prob [H,W] fp32: mean building probability over the covering tiles, mask [H,W] uint8)."""
+        h, w = self.window_size
+        img = ops.normalize_rgb_u8(rgb.contiguous()) if rgb.dtype == torch.uint8 else rgb.float().contiguous()
+        _, H, W = img.shape
+        rank, world = _dist_info(self.group)
+        wins = get_sliding_windows(H, W, self.window_size, self.overlap)
+        order = sorted(range(len(wins)), key=lambda i: (wins[i][0], wins[i][1]))
+        wins = [wins[i] for i in order]
+        plan = plan_bands([t[0] for t in wins], [t[2] - t[0] for t in wins], H, world) if wins else []
+        me = plan[rank] if rank < len(plan) else dict(first=0, last=0, lo=0, hi=0, own_lo=0, own_hi=0)
+        band = torch.zeros((2, max(1, me["hi"] - me["lo"]), W), dtype=torch.float32, device=img.device)   # [prob sum ; count]
+        demc = dem.float().contiguous()
+        for chunk in grouper(self.batch_size, wins[me["first"]:me["last"]]):
+            c4 = torch.tensor([(y, x, ye - y, xe - x) for y, x, ye, xe in chunk], dtype=torch.int32, device=img.device)
+            rgb_t, dem_t = ops.extract_tiles(img, demc, c4, h, w)              # reflect-pads short tiles
+            ops.tile_minmax_norm(dem_t)                                        # per-tile DSM min-max
+            logits = self.forward(rgb_t, dem_t).float().contiguous()
+            c4b = c4.clone()
+            c4b[:, 0] -= me["lo"]
+            ops.tile_prob_accumulate(band[0], band[1], logits, c4b.contiguous(), self.cls)
+        if world > 1 and rank < len(plan):
+            merge_bands(band, plan, rank, _device_add_rows, self.group)
+        prob = torch.zeros((H, W), dtype=torch.float32, device=img.device)
+        mask = torch.zeros((H, W), dtype=torch.uint8, device=img.device)
+        if me["own_hi"] > me["own_lo"]:
+            sl = slice(me["own_lo"] - me["lo"], me["own_hi"] - me["lo"])
+            p, m = ops.blend_finish(band[0, sl].contiguous(), band[1, sl].contiguous(), self.threshold)
+            prob[me["own_lo"]:me["own_hi"]], mask[me["own_lo"]:me["own_hi"]] = p, m
+        if world > 1:
+            dist.all_reduce(prob, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)
+        return prob, mask

@@ -603,3 +603,66 @@ def add3(a, b, c=None, out_dtype=torch.float32, out=None):
         out = torch.empty(a.shape, dtype=out_dtype, device=a.device)
     call("mfnet_add3", a.data_ptr(), _dt(a), b.data_ptr(), _dt(b), _p(c), _dt(c) if c is not None else 0, out.data_ptr(), _dt(out), a.numel(), _stream(a))
     return out
+
+
+# ------------------------------------------------------------------------------------------ raster inference
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def normalize_rgb_u8(img_u8, scale=1.0 / 255.0, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """[3,H,W] uint8 -> fp32 (x*scale - mean)/std  (inference.py:464-484)."""
+    import ctypes
+    _chk(img_u8)
+    assert img_u8.dtype == torch.uint8 and img_u8.is_contiguous() and img_u8.shape[0] == 3
+    out = torch.empty(img_u8.shape, dtype=torch.float32, device=img_u8.device)
+    m = (ctypes.c_float * 3)(*mean)
+    s = (ctypes.c_float * 3)(*std)
+    call("mfnet_normalize_rgb_u8", img_u8.data_ptr(), out.data_ptr(), img_u8.shape[1], img_u8.shape[2], float(scale),
+         ctypes.cast(m, ctypes.c_void_p), ctypes.cast(s, ctypes.c_void_p), _stream(img_u8))
+    return out
+
+
+def extract_tiles(rgb, dsm, coords4, h, w):
+    """rgb [C,H,W] fp32, dsm [H,W] fp32, coords4 [n,4] int32 (row, col, valid_h, valid_w) -> ([n,C,h,w], [n,h,w])."""
+    _chk(rgb, dsm, coords4)
+    assert rgb.is_contiguous() and dsm.is_contiguous() and rgb.dtype == dsm.dtype == torch.float32
+    assert coords4.dtype == torch.int32 and coords4.is_contiguous() and coords4.shape[1] == 4
+    C, H, W = rgb.shape
+    n = coords4.shape[0]
+    ro = torch.empty((n, C, h, w), dtype=torch.float32, device=rgb.device)
+    do = torch.empty((n, h, w), dtype=torch.float32, device=rgb.device)
+    call("mfnet_extract_tiles", rgb.data_ptr(), dsm.data_ptr(), coords4.data_ptr(), ro.data_ptr(), do.data_ptr(), n, C, H, W, h, w, _stream(rgb))
+    return ro, do
+
+
+def tile_minmax_norm(tiles):
+    _chk(tiles)
+    assert tiles.is_contiguous() and tiles.dtype == torch.float32
+    call("mfnet_tile_minmax_norm", tiles.data_ptr(), tiles.shape[0], tiles[0].numel(), _stream(tiles))
+    return tiles
+
+
+def tile_prob_accumulate(psum, cnt, logits, coords4, cls):
+    _chk(psum, cnt, logits, coords4)
+    assert psum.is_contiguous() and cnt.is_contiguous() and logits.is_contiguous() and logits.dtype == torch.float32
+    H, W = psum.shape
+    n, C, h, w = logits.shape
+    call("mfnet_tile_prob_accumulate", psum.data_ptr(), cnt.data_ptr(), logits.data_ptr(), coords4.data_ptr(), n, C, H, W, h, w, cls, _stream(psum))
+
+
+def blend_finish(psum, cnt, threshold):
+    _chk(psum, cnt)
+    prob = torch.empty_like(psum)
+    mask = torch.empty(psum.shape, dtype=torch.uint8, device=psum.device)
+    call("mfnet_blend_finish", psum.data_ptr(), cnt.data_ptr(), prob.data_ptr(), mask.data_ptr(), float(threshold), psum.numel(), _stream(psum))
+    return prob, mask
+
+
+def confusion(pred_u8, gt_i64, n_classes):
+    _chk(pred_u8, gt_i64)
+    assert pred_u8.dtype == torch.uint8 and gt_i64.dtype == torch.int64 and pred_u8.is_contiguous() and gt_i64.is_contiguous()
+    assert pred_u8.numel() == gt_i64.numel()
+    cm = torch.zeros((n_classes, n_classes), dtype=torch.int64, device=pred_u8.device)
+    call("mfnet_confusion", pred_u8.data_ptr(), gt_i64.data_ptr(), cm.data_ptr(), n_classes, pred_u8.numel(), _stream(pred_u8))
+    return cm

@@ -1,0 +1,170 @@
+"""Host-side logic that needs no GPU: window grids against the reference's own index lists (golden
+sliding.npz, generated from utils2.sliding_window / inference._get_sliding_windows), the band plan of the
+multi-GPU raster merge (brute-force simulation and a 2-process gloo run), the data-parallel gradient
+exchange of TrainEngine (2-process gloo: all-reduced bucket gradients == single-process gradients of the
+concatenated batch), and the LR schedule."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from helpers import golden
+from ssrs_amd import inference as INF
+
+
+def test_window_grids_match_reference_lists():
+    g = golden("sliding")
+    n = 0
+    for k in g.files:
+        if k.startswith("sw_"):
+            H, W, step, win = map(int, k.split("_")[1:])
+            got = np.array(list(INF.sliding_window((H, W), step, (win, win))))
+            assert np.array_equal(got, g[k]), k
+            assert INF.count_sliding_window((H, W), step, (win, win)) == len(g[k])
+            n += 1
+        elif k.startswith("inf_"):
+            H, W, ov = map(int, k.split("_")[1:])
+            assert np.array_equal(np.array(INF.get_sliding_windows(H, W, (256, 256), ov)), g[k]), k
+            n += 1
+    assert n >= 10
+    assert [len(c) for c in INF.grouper(3, range(10))] == list(g["grouper_10_3"])
+
+
+def _simulate(H, W, stride, win, world, C=2, seed=0):
+    rng = np.random.default_rng(seed)
+    coords = [(x, y) for x, y, _, _ in INF.sliding_window((H, W), stride, (win, win))]
+    tiles = rng.standard_normal((len(coords), C, win, win))
+    full = np.zeros((C, H, W))
+    for t, (r, c) in zip(tiles, coords):
+        full[:, r:r + win, c:c + win] += t
+    plan = INF.plan_bands([c[0] for c in coords], [win] * len(coords), H, world)
+    bands = []
+    for p in plan:
+        b = np.zeros((C, p["hi"] - p["lo"], W))
+        for i in range(p["first"], p["last"]):
+            r, c = coords[i]
+            b[:, r - p["lo"]:r - p["lo"] + win, c:c + win] += tiles[i]
+        bands.append(b)
+    return coords, tiles, full, plan, bands
+
+
+@pytest.mark.parametrize("H,W,stride,win,world", [(600, 700, 64, 256, 2), (600, 700, 64, 256, 4), (512, 512, 32, 256, 8),
+                                                   (256, 256, 64, 256, 4), (1024, 777, 100, 256, 3), (300, 1000, 192, 256, 8)])
+def test_band_plan_brute_force(H, W, stride, win, world):
+    coords, tiles, full, plan, bands = _simulate(H, W, stride, win, world)
+    # owned ranges partition [0, H)
+    assert plan[0]["own_lo"] == 0 and plan[-1]["own_hi"] == H
+    for a, b in zip(plan[:-1], plan[1:]):
+        assert a["own_hi"] == b["own_lo"] and a["last"] == b["first"]
+    # chain transfers in rank order
+    for r in range(len(plan) - 1):
+        p, q = plan[r], plan[r + 1]
+        k = p["hi"] - p["own_hi"]
+        if k > 0:
+            assert q["lo"] == p["own_hi"] and q["hi"] >= p["hi"]
+            bands[r + 1][:, :k, :] += bands[r][:, p["own_hi"] - p["lo"]:p["hi"] - p["lo"], :]
+    for p, b in zip(plan, bands):
+        own = b[:, p["own_lo"] - p["lo"]:p["own_hi"] - p["lo"], :]
+        np.testing.assert_allclose(own, full[:, p["own_lo"]:p["own_hi"], :], atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------ gloo, world 2
+def _init(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _merge_worker(rank, world, port, q):
+    _init(rank, world, port)
+    H, W, stride, win = 600, 700, 64, 256
+    coords, tiles, full, plan, bands = _simulate(H, W, stride, win, world)
+    band = torch.from_numpy(bands[rank]).clone()
+
+    def add_rows(dst, src):
+        dst[:, :src.shape[1], :] += src
+    INF.merge_bands(band, plan, rank, add_rows)
+    p = plan[rank]
+    own = band[:, p["own_lo"] - p["lo"]:p["own_hi"] - p["lo"], :].numpy()
+    q.put((rank, float(np.abs(own - full[:, p["own_lo"]:p["own_hi"], :]).max())))
+    dist.destroy_process_group()
+
+
+def _run(fn, world, port):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=fn, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return sorted(out)
+
+
+def test_band_merge_two_processes_gloo():
+    for rank, err in _run(_merge_worker, 2, 29611):
+        assert err < 1e-12, (rank, err)
+
+
+class _Toy(nn.Module):
+    """stand-in with the same top-level naming as MFNet: an 'image_encoder' part and a head part."""
+
+    def __init__(self):
+        super().__init__()
+        self.image_encoder = nn.Sequential(nn.Linear(12, 16), nn.Tanh(), nn.Linear(16, 16))
+        self.decoder = nn.Sequential(nn.Linear(16, 8), nn.Tanh(), nn.Linear(8, 3))
+        for p in self.image_encoder[0].parameters():
+            p.requires_grad = False                                        # frozen tensors stay out of the buckets
+
+    def forward(self, x):
+        return self.decoder(self.image_encoder(x))
+
+
+def _dp_worker(rank, world, port, q):
+    from ssrs_amd.trainer import TrainEngine
+    _init(rank, world, port)
+    torch.manual_seed(0)
+    ref_model = _Toy()
+    x = torch.randn(8, 12)
+    y = torch.randn(8, 3)
+    # single-process gradients on the whole batch (mean loss)
+    ref_model.zero_grad()
+    ((ref_model(x) - y) ** 2).mean().backward()
+    ref = {n: p.grad.clone() for n, p in ref_model.named_parameters() if p.grad is not None}
+    errs = []
+    for overlap in (True, False):
+        torch.manual_seed(0)
+        m = _Toy()
+        eng = TrainEngine(m, lr=0.1, momentum=0.9, weight_decay=0.0, overlap=overlap)
+        assert len(eng.bucket_bounds) == 2 and eng.world == world
+        eng.zero_grad()
+        sl = slice(rank * 4, (rank + 1) * 4)
+        ((m(x[sl]) - y[sl]) ** 2).mean().backward()
+        eng._finish_exchange()
+        for n, p in zip(eng.names, eng.params):
+            errs.append(float((p.grad / world - ref[n]).abs().max()))
+        assert all(n in ref for n in eng.names) and len(eng.names) == len(ref)
+    q.put((rank, max(errs)))
+    dist.destroy_process_group()
+
+
+def test_dp_gradient_exchange_two_processes_gloo():
+    for rank, err in _run(_dp_worker, 2, 29612):
+        assert err < 1e-6, (rank, err)
+
+
+def test_multistep_lr_schedule():
+    from ssrs_amd.trainer import TrainEngine
+    eng = TrainEngine(_Toy(), lr=0.01, milestones=(2, 4), gamma=0.1)
+    ref_opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.01)
+    sched = torch.optim.lr_scheduler.MultiStepLR(ref_opt, milestones=[2, 4], gamma=0.1)
+    for _ in range(6):
+        assert abs(eng.lr - ref_opt.param_groups[0]["lr"]) < 1e-12
+        ref_opt.step()
+        sched.step()
+        eng.scheduler_step()
