@@ -148,9 +148,17 @@ def main():
         ms = sum(t[0].elapsed_time(t[1]) for t in tr)
         fl = sum(t[2] for t in tr)
         achieved = fl / (ms * 1e-3) / 1e12
+        # HBM bytes per launch come from the PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read from inside the
+        # process): the newest profiles/*gemm_pmc.json, produced by tools/pmc_traffic.py from two rocprofv3 runs
+        traffic = None
+        import glob
+        pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "*gemm_pmc.json")))
+        if pmc and a.mod == "sam_lora" and a.batch == 16 and a.encoder == "vit_b":
+            with open(pmc[-1]) as f:
+                traffic = round(json.load(f)["traffic_bytes_per_launch"])
         roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(achieved, 2),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-                    "traffic": None, "launches_per_step": len(tr) // a.steps,
+                    "traffic": traffic, "launches_per_step": len(tr) // a.steps,
                     "avg_launch_us": round(1e3 * ms / len(tr), 2), "gflop_per_launch": round(fl / len(tr) / 1e9, 3),
                     "gemm_ms_per_step": round(ms / a.steps, 3)}
         if os.environ.get("MFNET_GEMM_SHAPES"):          # developer aid: per-shape GEMM time on stderr

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 counter passes into per-launch HBM traffic of one kernel.
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-roofline
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-roofline
+    python tools/pmc_traffic.py /tmp/pmc_f/f_counter_collection.csv /tmp/pmc_w/w_counter_collection.csv gemm_bf16_kernel profiles/rNN_gemm_pmc.json
+
+Corrections (MI355X_MICROARCH.md, "HBM"): the counters are in KiB; on gfx950 FETCH_SIZE reports half of the
+bytes of wide coalesced streaming reads (x2); WRITE_SIZE is exact for 16-B-per-lane stores."""
+import collections
+import csv
+import json
+import sys
+
+
+def per_kernel(path, counter):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            a = agg[r["Kernel_Name"]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    return agg
+
+
+def main():
+    fpath, wpath, kern, out = sys.argv[1:5]
+    f = {k: v for k, v in per_kernel(fpath, "FETCH_SIZE").items() if k.startswith(kern)}
+    w = {k: v for k, v in per_kernel(wpath, "WRITE_SIZE").items() if k.startswith(kern)}
+    nf, sf = map(sum, zip(*f.values()))
+    nw, sw = map(sum, zip(*w.values()))
+    d = {"kernel": kern, "dispatches": nf, "FETCH_SIZE_KB_per_launch_raw": sf / nf, "WRITE_SIZE_KB_per_launch_raw": sw / nw,
+         "corrections": "unit KiB; gfx950 FETCH_SIZE x2 for wide coalesced reads; WRITE_SIZE exact",
+         "read_bytes_per_launch": 2 * 1024 * sf / nf, "write_bytes_per_launch": 1024 * sw / nw,
+         "traffic_bytes_per_launch": 2 * 1024 * sf / nf + 1024 * sw / nw}
+    json.dump(d, open(out, "w"), indent=1)
+    print(json.dumps(d))
+
+
+if __name__ == "__main__":
+    main()
