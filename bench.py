@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--classes", type=int, default=6)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="do not capture the step into a HIP graph")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,7 +115,8 @@ def main():
     from ssrs_amd import detfill, ops
     from ssrs_amd.trainer import TrainEngine
     model = build_model(a.mod, a.encoder, a.classes, dev)
-    eng = TrainEngine(model, lr=0.01, momentum=0.9, weight_decay=5e-4, class_weight=torch.ones(a.classes, device=dev))
+    eng = TrainEngine(model, lr=0.01, momentum=0.9, weight_decay=5e-4, class_weight=torch.ones(a.classes, device=dev),
+                      use_graph=not a.eager)
     rgb, dsm, tgt = detfill.tiles(f"bench/rank{rank}", a.batch, 256, a.classes)
     rgb, dsm, tgt = rgb.to(dev), dsm.to(dev), tgt.to(dev)
 
@@ -123,7 +125,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for _ in range(max(a.warmup, 3 if eng.use_graph else 0)):      # graph mode: 2 eager steps + the capture are never timed
         acc = eng.step(rgb, dsm, tgt)
     sync()
     t0 = time.perf_counter()
@@ -139,7 +141,8 @@ def main():
 
     roofline = None
     if rank == 0 and not a.no_roofline:
-        # second pass over the same steps with an event pair around every GEMM launch
+        # second pass over the same steps, eagerly, with an event pair around every GEMM launch
+        eng.use_graph = False
         ops.GEMM_TRACE = []
         for _ in range(a.steps):
             eng.step(rgb, dsm, tgt)

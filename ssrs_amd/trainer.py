@@ -82,7 +82,7 @@ class TrainEngine:
 
     def __init__(self, model: nn.Module, lr: float = 0.01, momentum: float = 0.9, weight_decay: float = 5e-4,
                  milestones: Sequence[int] = (25, 35, 45), gamma: float = 0.1, class_weight: Optional[torch.Tensor] = None,
-                 ignore_index: int = -100, process_group=None, overlap: bool = True):
+                 ignore_index: int = -100, process_group=None, overlap: bool = True, use_graph: bool = False):
         self.model = model
         self.base_lr, self.momentum, self.weight_decay = float(lr), float(momentum), float(weight_decay)
         self.milestones, self.gamma = sorted(int(m) for m in milestones), float(gamma)
@@ -91,7 +91,13 @@ class TrainEngine:
         self.class_weight = class_weight
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
-        self.overlap = overlap
+        # use_graph: zero_grad + forward + loss + backward are captured once per input shape into a HIP graph
+        # and replayed (the step is ~2300 kernel launches: eager host enqueue time is 23 ms of a 29 ms step).
+        # The gradient exchange and the SGD kernel (whose lr changes with the schedule) stay outside the graph.
+        self.use_graph = bool(use_graph)
+        self.overlap = overlap and not self.use_graph        # autograd hooks do not run when a graph is replayed
+        self._graphs = {}
+        self._eager_warmup = 2
         named, n_head = trainable_tensors(model)
         if not named:
             raise ValueError("model has no trainable tensors")
@@ -121,7 +127,7 @@ class TrainEngine:
         self._works = []
         self._bucket_size = [self.bucket_of.count(b) for b in range(len(self.bucket_bounds))]
         self._hooks = []
-        if self.world > 1:
+        if self.world > 1 and not self.use_graph:
             for i, p in enumerate(self.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(self.bucket_of[i])))
         self.steps = 0
@@ -178,11 +184,40 @@ class TrainEngine:
 
     def step(self, rgb: torch.Tensor, dsm: torch.Tensor, target: torch.Tensor):
         """zero_grad -> forward -> CE -> backward (-> all-reduce) -> SGD. Returns the device tensor
-        [sum w*nll, sum w, #correct, #valid] of THIS rank's batch; nothing is synchronised."""
-        self.zero_grad()
-        acc, _ = self.forward_backward(rgb, dsm, target)
+        [sum w*nll, sum w, #correct, #valid] of THIS rank's batch; nothing is synchronised. In graph mode
+        the returned tensor is overwritten by the next step of the same input shape."""
+        if self.use_graph:
+            acc = self._graph_forward_backward(rgb, dsm, target)
+        else:
+            self.zero_grad()
+            acc, _ = self.forward_backward(rgb, dsm, target)
         self.optimizer_step()
         self.steps += 1
+        return acc
+
+    def _graph_forward_backward(self, rgb, dsm, target):
+        key = (tuple(rgb.shape), tuple(dsm.shape), tuple(target.shape), self.model.training)
+        ent = self._graphs.get(key)
+        if ent is None:
+            if self._eager_warmup > 0:           # builds the frozen-weight caches and kernel attributes outside any capture
+                self._eager_warmup -= 1
+                self.zero_grad()
+                return self.forward_backward(rgb, dsm, target)[0]
+            srgb, sdsm, stgt = rgb.clone(), dsm.clone(), target.clone()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.zero_grad()
+                acc, _ = self.forward_backward(srgb, sdsm, stgt)
+            ent = self._graphs[key] = (g, srgb, sdsm, stgt, acc)
+        g, srgb, sdsm, stgt, acc = ent
+        if rgb.data_ptr() != srgb.data_ptr():
+            srgb.copy_(rgb, non_blocking=True)
+        if dsm.data_ptr() != sdsm.data_ptr():
+            sdsm.copy_(dsm, non_blocking=True)
+        if target.data_ptr() != stgt.data_ptr():
+            stgt.copy_(target, non_blocking=True)
+        g.replay()
         return acc
 
     @staticmethod

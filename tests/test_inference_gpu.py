@@ -119,6 +119,28 @@ def test_train_engine_two_steps_vs_reference_losses():
     assert eng.params[0].data_ptr() == eng.flat_p.data_ptr()
 
 
+def test_train_engine_graph_mode_matches_eager():
+    """the HIP-graph replay of zero_grad + forward + loss + backward gives the same training trajectory as the
+    eager launches (float atomics in the reductions make it equal only to rounding)."""
+    from ssrs_amd.trainer import TrainEngine
+    rgb, dsm, tgt = [t.cuda() for t in detfill.tiles("graph", 2, 256, 6)]
+    losses = {}
+    for mode in (False, True):
+        m = _tiny()
+        m.load_state_dict(detfill.fill_state_dict(m.state_dict(), "graph/"))
+        m = m.cuda().train()
+        m.decoder.segmentation_head[1].p = 0.0
+        eng = TrainEngine(m, lr=0.01, momentum=0.9, weight_decay=5e-4, class_weight=torch.ones(6, device="cuda"), use_graph=mode)
+        losses[mode] = [TrainEngine.read_metrics(eng.step(rgb, dsm, tgt))["loss"] for _ in range(6)]
+        if mode:
+            assert len(eng._graphs) == 1
+            nbt = m.decoder.b4.norm1.num_batches_tracked.item()
+            assert nbt == 6, nbt                  # capture itself executes nothing: 2 eager + 4 replayed steps
+    for a, b in zip(losses[False], losses[True]):
+        assert abs(a - b) < 2e-3 * abs(a), (losses[False], losses[True])
+    assert losses[True][-1] < losses[True][0]
+
+
 def test_confusion_and_metrics():
     from ssrs_amd import ops
     from ssrs_amd.inference import metrics_from_confusion
