@@ -74,16 +74,19 @@ int mfnet_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int6
                     int64_t res_row_mod, void* out, int out_dtype, int64_t ldc, int k_splits, hipStream_t stream);
 
 /* ---- skinny products of the low-rank paths (layers.py:149-165,244-268 forward "x @ A^T" and the
- * wgrads of lora_A / lora_B). nt: out[m,j] = scale * sum_k X[m,k] Wt[j,k], X bf16 [M,K], Wt fp32 [R,K],
- * R <= 16. tn: out[c,j] (or out[j,c] if transposed) += scale * sum_m Y[m,c] U[m,j], Y bf16 [M,C], U fp32
- * [M,R] (accumulates: zero `out` first). */
-int mfnet_skinny_nt(const void* X, int64_t ldx, const float* Wt, int64_t ldw, float* out, int64_t ldo,
-                    int64_t M, int64_t K, int R, float scale, hipStream_t stream);
+ * wgrads of lora_A / lora_B). nt (MFMA): out[m,j] = scale * sum_k X[m,k] Wt[g(m)][j,k], X bf16 [M,K], Wt fp32
+ * [n_groups][R,K] (group stride w_group_stride elements; g(m) = (m / rows_per_group) % n_groups: the per-modality
+ * LoRA matrices), R <= 16, K % 32 == 0, ldo % 4 == 0. tn: for each group z < n_groups, out_z[c,j] (or out_z[j,c]
+ * if transposed) += scale * sum_{m < M} Y[z*M+m, c] U[z*M+m, j]; Y bf16, U fp32 [.,R], out_z = out +
+ * z*out_group_stride (accumulates: zero `out` first). */
+int mfnet_skinny_nt(const void* X, int64_t ldx, const float* Wt, int64_t ldw, int64_t w_group_stride, int64_t rows_per_group,
+                    int n_groups, float* out, int64_t ldo, int64_t M, int64_t K, int R, float scale, hipStream_t stream);
 int mfnet_skinny_tn(const void* Y, int64_t ldy, const float* U, int64_t ldu, float* out, int64_t M, int64_t C,
-                    int R, int transposed, float scale, float* workspace, int64_t workspace_floats, hipStream_t stream);
+                    int R, int transposed, float scale, int n_groups, int64_t out_group_stride, float* workspace,
+                    int64_t workspace_floats, hipStream_t stream);
 /* scratch floats that make mfnet_skinny_tn atomic-free and deterministic (two-stage row reduction); with a
  * null workspace the row splits meet in float atomics on `out`. */
-int64_t mfnet_skinny_tn_workspace_floats(int64_t M, int64_t C, int R);
+int64_t mfnet_skinny_tn_workspace_floats(int64_t M, int64_t C, int R, int n_groups);
 
 /* ---- LoRA cross-modal mix (layers.py:159-160): a [M,r] fp32 = [x@Ax^T ; y@Ay^T] (RGB rows first) ->
  * U [M,2r]: RGB rows [wx*ax, (1-wx)*ay], DSM rows [(1-wy)*ax, wy*ay]; backward returns da and ADDS

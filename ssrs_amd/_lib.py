@@ -33,8 +33,8 @@ _SIGS = {
     "mfnet_layernorm_bwd": [P, I, I64, P, I, I64, P, P, P, P, P, P, I64, P, P, I64, I64, P],
     "mfnet_gemm_bf16": [P, I64, P, I64, I64, I64, I64, P, P, I64, P, I64, I64, I, I, F, I, P, I64, P, I64,
                         P, I64, I64, P, I, I64, I, P],
-    "mfnet_skinny_nt": [P, I64, P, I64, P, I64, I64, I64, I, F, P],
-    "mfnet_skinny_tn": [P, I64, P, I64, P, I64, I64, I, I, F, P, I64, P],
+    "mfnet_skinny_nt": [P, I64, P, I64, I64, I64, I, P, I64, I64, I64, I, F, P],
+    "mfnet_skinny_tn": [P, I64, P, I64, P, I64, I64, I, I, F, I, I64, P, I64, P],
     "mfnet_cast": [P, I, P, I, I64, P],
     "mfnet_im2col_patch": [P, P, P, I64, I64, I64, I64, P],
     "mfnet_im2col3x3": [P, P, I64, I64, I64, I64, P],
@@ -110,7 +110,7 @@ def lib():
         L.mfnet_version.restype = c_int
         L.mfnet_version.argtypes = []
         L.mfnet_skinny_tn_workspace_floats.restype = c_int64
-        L.mfnet_skinny_tn_workspace_floats.argtypes = [c_int64, c_int64, c_int]
+        L.mfnet_skinny_tn_workspace_floats.argtypes = [c_int64, c_int64, c_int, c_int]
         for name, sig in _SIGS.items():
             fn = getattr(L, name, None)
             if fn is None:

@@ -2,63 +2,63 @@
 // big bf16 token matrix exactly once (algorithmic bytes = M*K*2) and keeps the rank-R side in
 // registers.
 //
-//   skinny_nt : out[m, j]  = sum_k X[m,k] * Wt[j,k]      X bf16 [M,K], Wt fp32 [R,K]  -> fp32 [M,R]
+//   skinny_nt : out[m, j]  = sum_k X[m,k] * Wt[g][j,k]   X bf16 [M,K], Wt fp32 [G][R,K] -> fp32 [M,R]  (MFMA)
 //               (LoRA down-projection  x @ A^T,  loralib/layers.py:157-158,253,261; and  g @ B  in bwd)
 //   skinny_tn : out[c, j] += sum_m Y[m,c] * U[m,j]        Y bf16 [M,C], U fp32 [M,R]   -> fp32 [C,R] or [R,C]
 //               (LoRA weight grads  dB = g^T u,  dA = da^T x)
 #include "common.h"
 
-#define SK_ROWS 8
-
-template <int R>
-__global__ __launch_bounds__(256) void skinny_nt_kernel(const bf16_t* __restrict__ X, int64_t ldx,
-                                                        const float* __restrict__ Wt, int64_t ldw,
-                                                        float* __restrict__ out, int64_t ldo, int64_t M, int K,
-                                                        float scale) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * SK_ROWS;
-  if (row0 >= M) return;
-  float acc[SK_ROWS][R];
-#pragma unroll
-  for (int r = 0; r < SK_ROWS; ++r)
-#pragma unroll
-    for (int j = 0; j < R; ++j) acc[r][j] = 0.f;
-  const int nch = K >> 3;
-  for (int c = lane; c < nch; c += 64) {
-    float w[R][8];
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-      const float4 a = *reinterpret_cast<const float4*>(Wt + (int64_t)j * ldw + 8 * c);
-      const float4 b = *reinterpret_cast<const float4*>(Wt + (int64_t)j * ldw + 8 * c + 4);
-      w[j][0] = a.x; w[j][1] = a.y; w[j][2] = a.z; w[j][3] = a.w;
-      w[j][4] = b.x; w[j][5] = b.y; w[j][6] = b.z; w[j][7] = b.w;
+// out[m, j] = scale * sum_k X[m,k] * Wt[g(m)][j,k] on the matrix cores: the fp32 rank-R matrix is converted to
+// bf16 fragments in registers (rows >= R are zero), a block owns 16 rows of X and its 4 waves split K; the
+// accumulator tile is C[j][m], so each lane ends with 4 consecutive j of one row (one float4 store).
+__global__ __launch_bounds__(256) void skinny_nt_kernel(const bf16_t* __restrict__ X, int64_t ldx, const float* __restrict__ Wt,
+                                                        int64_t ldw, int64_t w_group_stride, int64_t rows_per_group, int n_groups,
+                                                        float* __restrict__ out, int64_t ldo, int64_t M, int K, int R, float scale) {
+  __shared__ float red[3][64][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int64_t m0 = (int64_t)blockIdx.x * 16;
+  const int g = n_groups > 1 ? (int)((m0 / rows_per_group) % n_groups) : 0;
+  int64_t m = m0 + fr;
+  m = m < M ? m : M - 1;
+  const bf16_t* xp = X + m * ldx + 8 * fq;
+  const float* wp = Wt + (int64_t)g * w_group_stride + (int64_t)fr * ldw + 8 * fq;
+  const bool wok = fr < R;
+  f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int nsteps = K >> 5;
+  auto wfrag = [&](int s) {
+    union { bf16x8_t v; unsigned int w[4]; } wf;
+    wf.w[0] = wf.w[1] = wf.w[2] = wf.w[3] = 0u;
+    if (wok) {
+      const float4 a = *reinterpret_cast<const float4*>(wp + 32 * s), b = *reinterpret_cast<const float4*>(wp + 32 * s + 4);
+      wf.w[0] = pack_bf16x2(a.x, a.y); wf.w[1] = pack_bf16x2(a.z, a.w); wf.w[2] = pack_bf16x2(b.x, b.y); wf.w[3] = pack_bf16x2(b.z, b.w);
     }
-#pragma unroll
-    for (int r = 0; r < SK_ROWS; ++r) {
-      int64_t m = row0 + r;
-      m = m < M ? m : M - 1;
-      const u32x4_t xv = *reinterpret_cast<const u32x4_t*>(X + m * ldx + 8 * c);
-      const float x[8] = {bf16_lo(xv.x), bf16_hi(xv.x), bf16_lo(xv.y), bf16_hi(xv.y),
-                          bf16_lo(xv.z), bf16_hi(xv.z), bf16_lo(xv.w), bf16_hi(xv.w)};
-#pragma unroll
-      for (int j = 0; j < R; ++j) {
-        float s = acc[r][j];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += x[e] * w[j][e];
-        acc[r][j] = s;
-      }
-    }
+    return wf.v;
+  };
+  int s = wave;
+  for (; s + 12 < nsteps; s += 16) {          // four k-steps in flight per wave
+    const bf16x8_t x0 = *reinterpret_cast<const bf16x8_t*>(xp + 32 * s), x1 = *reinterpret_cast<const bf16x8_t*>(xp + 32 * (s + 4));
+    const bf16x8_t x2 = *reinterpret_cast<const bf16x8_t*>(xp + 32 * (s + 8)), x3 = *reinterpret_cast<const bf16x8_t*>(xp + 32 * (s + 12));
+    const bf16x8_t w0 = wfrag(s), w1 = wfrag(s + 4), w2 = wfrag(s + 8), w3 = wfrag(s + 12);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, x2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3, x3, acc, 0, 0, 0);
   }
+  for (; s < nsteps; s += 4)
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag(s), *reinterpret_cast<const bf16x8_t*>(xp + 32 * s), acc, 0, 0, 0);
+  if (wave > 0) {
+    red[wave - 1][lane][0] = acc[0]; red[wave - 1][lane][1] = acc[1]; red[wave - 1][lane][2] = acc[2]; red[wave - 1][lane][3] = acc[3];
+  }
+  __syncthreads();
+  if (wave == 0 && m0 + fr < M) {
 #pragma unroll
-  for (int r = 0; r < SK_ROWS; ++r)
-#pragma unroll
-    for (int j = 0; j < R; ++j) acc[r][j] = wave_sum(acc[r][j]);
-  // lane l < SK_ROWS*R writes element (r = l / R, j = l % R)
-#pragma unroll
-  for (int r = 0; r < SK_ROWS; ++r)
-#pragma unroll
-    for (int j = 0; j < R; ++j)
-      if (lane == ((r * R + j) & 63) && row0 + r < M) out[(row0 + r) * ldo + j] = acc[r][j] * scale;
+    for (int w = 0; w < 3; ++w) { acc[0] += red[w][lane][0]; acc[1] += red[w][lane][1]; acc[2] += red[w][lane][2]; acc[3] += red[w][lane][3]; }
+    float* op = out + (m0 + fr) * ldo + 4 * fq;      // j = 4*fq + r
+    if (4 * fq + 3 < R) *reinterpret_cast<float4*>(op) = make_float4(acc[0] * scale, acc[1] * scale, acc[2] * scale, acc[3] * scale);
+    else
+      for (int r = 0; r < 4; ++r) if (4 * fq + r < R) op[r] = acc[r] * scale;
+  }
 }
 
 // grid: (col strips of 512, row splits); block = 4 waves sharing the strip, each wave a row slice.
@@ -70,12 +70,17 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* __restrict
                                                         const float* __restrict__ U, int64_t ldu,
                                                         float* __restrict__ out, int64_t M, int C,
                                                         int64_t rows_per_block, int transposed, float scale,
-                                                        float* __restrict__ partial) {
+                                                        float* __restrict__ partial, int64_t group_rows, int64_t out_group_stride) {
+  // blockIdx.z = group: rows [z*group_rows, (z+1)*group_rows) of Y / U reduce into out + z*out_group_stride
   __shared__ float red[64][8 * R + 1];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int c0 = (blockIdx.x * 64 + lane) * 8;
   const bool active = c0 < C;
+  Y += (int64_t)blockIdx.z * group_rows * ldy;
+  U += (int64_t)blockIdx.z * group_rows * ldu;
+  out += (int64_t)blockIdx.z * out_group_stride;
+  if (partial) partial += (int64_t)blockIdx.z * gridDim.y * C * R;
   const int64_t r_begin = (int64_t)blockIdx.y * rows_per_block;
   int64_t r_end = r_begin + rows_per_block;
   if (r_end > M) r_end = M;
@@ -138,22 +143,30 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* __restrict
   }
 }
 
-// out[c, j] (or out[j, c]) += scale * sum_s partial[s][c][j]
+// out[g][c, j] (or out[g][j, c]) += scale * sum_s partial[g][s][c][j]; four independent partial sums per thread
 __global__ __launch_bounds__(256) void skinny_tn_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int C, int R,
-                                                               int splits, int transposed, float scale) {
+                                                               int splits, int transposed, float scale, int64_t out_group_stride) {
   const int64_t n = (int64_t)C * R;
+  partial += (int64_t)blockIdx.y * splits * n;
+  out += (int64_t)blockIdx.y * out_group_stride;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    float a = 0.f;
-    for (int s = 0; s < splits; ++s) a += partial[(int64_t)s * n + i];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = 0;
+    for (; s + 3 < splits; s += 4) {
+      a0 += partial[(int64_t)s * n + i]; a1 += partial[(int64_t)(s + 1) * n + i];
+      a2 += partial[(int64_t)(s + 2) * n + i]; a3 += partial[(int64_t)(s + 3) * n + i];
+    }
+    for (; s < splits; ++s) a0 += partial[(int64_t)s * n + i];
     const int c = (int)(i / R), j = (int)(i - (int64_t)c * R);
     float* o = transposed ? out + (int64_t)j * C + c : out + i;
-    *o += a * scale;
+    *o += (a0 + a1 + a2 + a3) * scale;
   }
 }
 
 static void skinny_tn_geometry(int64_t M, int64_t C, int64_t* strips, int64_t* splits, int64_t* rpb) {
   *strips = ceil_div64(C, 512);
-  int64_t sp = ceil_div64(256, *strips);              // aim for ~256 workgroups (one per CU)
+  int64_t sp = ceil_div64(128, *strips);              // ~128 workgroups per group (two groups per launch)
+  if (sp > 32) sp = 32;                               // the second stage sums at most 32 partials per output
   int64_t r = ceil_div64(M, sp);
   if (r < 64) r = 64;
   r = ceil_div64(r, 4) * 4;
@@ -161,24 +174,25 @@ static void skinny_tn_geometry(int64_t M, int64_t C, int64_t* strips, int64_t* s
   *splits = ceil_div64(M, r);
 }
 // floats of scratch that make mfnet_skinny_tn deterministic and atomic-free (two-stage reduction)
-extern "C" int64_t mfnet_skinny_tn_workspace_floats(int64_t M, int64_t C, int R) {
-  if (M <= 0 || C <= 0 || R <= 0) return 0;
+extern "C" int64_t mfnet_skinny_tn_workspace_floats(int64_t M, int64_t C, int R, int n_groups) {
+  if (M <= 0 || C <= 0 || R <= 0 || n_groups <= 0) return 0;
   int64_t strips, splits, rpb;
   skinny_tn_geometry(M, C, &strips, &splits, &rpb);
-  return splits * C * R;
+  return n_groups * splits * C * R;
 }
 
-extern "C" int mfnet_skinny_nt(const void* X, int64_t ldx, const float* Wt, int64_t ldw, float* out,
-                               int64_t ldo, int64_t M, int64_t K, int R, float scale, hipStream_t stream) {
+extern "C" int mfnet_skinny_nt(const void* X, int64_t ldx, const float* Wt, int64_t ldw, int64_t w_group_stride,
+                               int64_t rows_per_group, int n_groups, float* out, int64_t ldo, int64_t M, int64_t K, int R,
+                               float scale, hipStream_t stream) {
   MF_CHECK_ARG(X && Wt && out, "skinny_nt: null pointer");
-  MF_CHECK_ARG(K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldw % 4 == 0 && ldx >= K && ldw >= K, "skinny_nt: bad K/ld");
-  MF_CHECK_ARG(R == 4 || R == 8 || R == 16, "skinny_nt: R=%d must be 4, 8 or 16", R);
-  MF_CHECK_ARG(ldo >= R, "skinny_nt: bad ldo");
+  MF_CHECK_ARG(K > 0 && K % 32 == 0 && ldx % 8 == 0 && ldw % 4 == 0 && ldx >= K && ldw >= K, "skinny_nt: K=%lld must be a multiple of 32 (ld multiples of 8 / 4)", (long long)K);
+  MF_CHECK_ARG(R >= 1 && R <= 16, "skinny_nt: R=%d must be in [1, 16]", R);
+  MF_CHECK_ARG(ldo >= R && ldo % 4 == 0, "skinny_nt: ldo must be >= R and a multiple of 4");
+  MF_CHECK_ARG(n_groups >= 1 && (n_groups == 1 || (rows_per_group > 0 && rows_per_group % 16 == 0)), "skinny_nt: rows_per_group must be a multiple of 16");
+  MF_CHECK_ARG(K < (1ll << 31), "skinny_nt: K too large");
   if (M <= 0) return MFNET_OK;
-  dim3 grid((unsigned)ceil_div64(M, 4 * SK_ROWS)), block(256);
-#define SKNT(RR) hipLaunchKernelGGL((skinny_nt_kernel<RR>), grid, block, 0, stream, (const bf16_t*)X, ldx, Wt, ldw, out, ldo, M, (int)K, scale)
-  if (R == 4) SKNT(4); else if (R == 8) SKNT(8); else SKNT(16);
-#undef SKNT
+  hipLaunchKernelGGL(skinny_nt_kernel, dim3((unsigned)ceil_div64(M, 16)), dim3(256), 0, stream, (const bf16_t*)X, ldx, Wt, ldw, w_group_stride,
+                     rows_per_group, n_groups, out, ldo, M, (int)K, R, scale);
   MF_LAUNCH_CHECK("skinny_nt");
   return MFNET_OK;
 }
@@ -187,27 +201,29 @@ extern "C" int mfnet_skinny_nt(const void* X, int64_t ldx, const float* Wt, int6
 // mfnet_skinny_tn_workspace_floats(M, C, R) floats the reduction over row splits is two-stage (plain stores +
 // one small reduce kernel: deterministic); without it the splits meet in float atomics on `out`.
 extern "C" int mfnet_skinny_tn(const void* Y, int64_t ldy, const float* U, int64_t ldu, float* out,
-                               int64_t M, int64_t C, int R, int transposed, float scale, float* workspace,
-                               int64_t workspace_floats, hipStream_t stream) {
+                               int64_t M, int64_t C, int R, int transposed, float scale, int n_groups,
+                               int64_t out_group_stride, float* workspace, int64_t workspace_floats, hipStream_t stream) {
+  // M = rows PER GROUP; group z reads rows [z*M, (z+1)*M) and accumulates into out + z*out_group_stride
   MF_CHECK_ARG(Y && U && out, "skinny_tn: null pointer");
   MF_CHECK_ARG(C > 0 && C % 8 == 0 && ldy % 8 == 0 && ldy >= C, "skinny_tn: bad C/ldy");
   MF_CHECK_ARG(R == 4 || R == 8 || R == 16, "skinny_tn: R=%d must be 4, 8 or 16", R);
   MF_CHECK_ARG(ldu >= R && ldu % 4 == 0, "skinny_tn: bad ldu");
+  MF_CHECK_ARG(n_groups >= 1 && n_groups <= 64 && (n_groups == 1 || out_group_stride >= C * R), "skinny_tn: bad group args");
   if (M <= 0) return MFNET_OK;
   int64_t strips, splits, rpb;
   skinny_tn_geometry(M, C, &strips, &splits, &rpb);
   float* partial = nullptr;
   if (workspace) {
-    MF_CHECK_ARG(workspace_floats >= splits * C * R, "skinny_tn: workspace too small (%lld < %lld floats)", (long long)workspace_floats, (long long)(splits * C * R));
+    MF_CHECK_ARG(workspace_floats >= n_groups * splits * C * R, "skinny_tn: workspace too small (%lld < %lld floats)", (long long)workspace_floats, (long long)(n_groups * splits * C * R));
     partial = workspace;
   }
-  dim3 grid((unsigned)strips, (unsigned)splits), block(256);
-#define SKTN(RR) hipLaunchKernelGGL((skinny_tn_kernel<RR>), grid, block, 0, stream, (const bf16_t*)Y, ldy, U, ldu, out, M, (int)C, rpb, transposed, scale, partial)
+  dim3 grid((unsigned)strips, (unsigned)splits, (unsigned)n_groups), block(256);
+#define SKTN(RR) hipLaunchKernelGGL((skinny_tn_kernel<RR>), grid, block, 0, stream, (const bf16_t*)Y, ldy, U, ldu, out, M, (int)C, rpb, transposed, scale, partial, M, out_group_stride)
   if (R == 4) SKTN(4); else if (R == 8) SKTN(8); else SKTN(16);
 #undef SKTN
   if (partial) {
     int64_t g = ceil_div64(C * R, 256);
-    hipLaunchKernelGGL(skinny_tn_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, partial, out, (int)C, R, (int)splits, transposed, scale);
+    hipLaunchKernelGGL(skinny_tn_reduce_kernel, dim3((unsigned)g, (unsigned)n_groups), dim3(256), 0, stream, partial, out, (int)C, R, (int)splits, transposed, scale, out_group_stride);
   }
   MF_LAUNCH_CHECK("skinny_tn");
   return MFNET_OK;

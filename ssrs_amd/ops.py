@@ -112,33 +112,38 @@ def gemm(a, w, *, bias=None, U=None, V=None, rows_per_group=0, n_groups=1, lr_sc
     return (out, pre) if want_pre else out
 
 
-def skinny_nt(x, wt, scale=1.0, out=None):
-    """out[m, j] = scale * sum_k x[m,k] wt[j,k]; x bf16 [M,K], wt fp32 [R,K] -> fp32 [M,R]."""
+def skinny_nt(x, wt, scale=1.0, out=None, rows_per_group=0):
+    """out[m, j] = scale * sum_k x[m,k] wt[g(m)][j,k]; x bf16 [M,K]; wt fp32 [R,K] or [G,R,K] with
+    g(m) = m // rows_per_group (per-modality matrices) -> fp32 [M, R] (row stride a multiple of 4)."""
     _chk(x, wt, out)
     x2, M, K, ldx = _rows2d(x)
-    R = wt.shape[0]
-    assert wt.dtype == torch.float32 and wt.stride(1) == 1 and wt.shape[1] == K
+    G = wt.shape[0] if wt.dim() == 3 else 1
+    R = wt.shape[-2]
+    assert wt.dtype == torch.float32 and wt.is_contiguous() and wt.shape[-1] == K
     if out is None:
-        out = torch.empty((M, R), dtype=torch.float32, device=x.device)
-    call("mfnet_skinny_nt", x2.data_ptr(), ldx, wt.data_ptr(), wt.stride(0), out.data_ptr(), out.stride(0),
-         M, K, R, float(scale), _stream(x))
+        Rp = (R + 3) // 4 * 4
+        out = torch.empty((M, Rp), dtype=torch.float32, device=x.device)[:, :R]
+    call("mfnet_skinny_nt", x2.data_ptr(), ldx, wt.data_ptr(), K, R * K, rows_per_group if G > 1 else 0, G, out.data_ptr(),
+         out.stride(0), M, K, R, float(scale), _stream(x))
     return out
 
 
-def skinny_tn(y, u, transposed: bool, scale=1.0, out=None):
-    """out[c, j] (or [j, c] if transposed) += scale * sum_m y[m,c] u[m,j]; y bf16 [M,C], u fp32 [M,R]."""
+def skinny_tn(y, u, transposed: bool, scale=1.0, out=None, n_groups=1):
+    """per group z (rows [z*M/G, (z+1)*M/G)): out[z][c, j] (or [j, c] if transposed) += scale * sum_m y[m,c] u[m,j];
+    y bf16 [M,C], u fp32 [M,R]. Returns [G, C, R] / [G, R, C] (the leading dim is dropped for n_groups == 1)."""
     _chk(y, u, out)
     y2, M, C, ldy = _rows2d(y)
     R = u.shape[1]
-    assert u.dtype == torch.float32 and u.stride(1) == 1 and u.shape[0] == M
+    assert u.dtype == torch.float32 and u.stride(1) == 1 and u.shape[0] == M and M % n_groups == 0
     if out is None:
-        out = torch.zeros((R, C) if transposed else (C, R), dtype=torch.float32, device=y.device)
+        out = torch.zeros((n_groups, R, C) if transposed else (n_groups, C, R), dtype=torch.float32, device=y.device)
     assert out.is_contiguous()
-    nws = _lib.lib().mfnet_skinny_tn_workspace_floats(M, C, R)
+    Mg = M // n_groups
+    nws = _lib.lib().mfnet_skinny_tn_workspace_floats(Mg, C, R, n_groups)
     ws = torch.empty(nws, dtype=torch.float32, device=y.device)
-    call("mfnet_skinny_tn", y2.data_ptr(), ldy, u.data_ptr(), u.stride(0), out.data_ptr(), M, C, R,
-         1 if transposed else 0, float(scale), ws.data_ptr(), nws, _stream(y))
-    return out
+    call("mfnet_skinny_tn", y2.data_ptr(), ldy, u.data_ptr(), u.stride(0), out.data_ptr(), Mg, C, R,
+         1 if transposed else 0, float(scale), n_groups, C * R, ws.data_ptr(), nws, _stream(y))
+    return out[0] if (n_groups == 1 and out.dim() == 3) else out
 
 
 def cast(x, dtype):

@@ -85,16 +85,12 @@ def _rel_tables(attn: nn.Module, kh: int, kw: int):
 # ---------------------------------------------------------------------------------------------
 def _down(x_bf, A_x, A_y, half):
     """a[m] = x[m] @ A_g^T with the modality-specific A (rows [0,half) -> A_x, rest -> A_y)."""
-    r = A_x.shape[0]
-    a = torch.empty((x_bf.shape[0], r), dtype=torch.float32, device=x_bf.device)
-    ops.skinny_nt(x_bf[:half], A_x, out=a[:half])
-    ops.skinny_nt(x_bf[half:], A_y, out=a[half:])
-    return a
+    return ops.skinny_nt(x_bf, torch.stack([A_x.detach(), A_y.detach()]), rows_per_group=half).contiguous()
 
 
 def _tn_groups(y_bf, u, half, transposed, scale=1.0):
-    return (ops.skinny_tn(y_bf[:half], u[:half], transposed, scale),
-            ops.skinny_tn(y_bf[half:], u[half:], transposed, scale))
+    o = ops.skinny_tn(y_bf, u, transposed, scale, n_groups=2)
+    return o[0], o[1]
 
 
 def _attention(qkv, attn_mod, G, Sh, Sw, heads, ws):
@@ -145,9 +141,7 @@ class _LoraAttnBranch(torch.autograd.Function):
         dO = ops.gemm(d_bf, wT_bf16(attn.proj.weight))
         dqkv = ops.attn_bwd(qkv, attn.qkv.bias, tbl, tblT, o, dO, lse, 2 * B, Sh, Sw, heads, ws, Lh, Lw, hd ** -0.5)
         s = 1.0 / r
-        da = torch.empty_like(a)
-        for g, sl in enumerate((slice(0, half), slice(half, M))):
-            ops.skinny_nt(dqkv[sl], V[g].t().contiguous(), scale=s, out=da[sl])
+        da = ops.skinny_nt(dqkv, V.transpose(1, 2).contiguous(), scale=s, rows_per_group=half).contiguous()
         dVx, dVy = _tn_groups(dqkv, a, half, False, s)
         dBx = torch.cat([dVx[:D, :r], dVx[2 * D:, r:]], 0)
         dBy = torch.cat([dVy[:D, :r], dVy[2 * D:, r:]], 0)

@@ -126,12 +126,25 @@ def test_skinny(ops, M, K, R):
     x = rnd(M, K, seed=1).to(torch.bfloat16)
     wt = rnd(R, K, seed=2)
     out = ops.skinny_nt(x, wt, scale=0.5)
-    assert rel_err(out, 0.5 * (x.double() @ wt.double().t())) < 1e-5
+    # the rank-R matrix is rounded to bf16 fragments for the MFMA: exact against the rounded operand
+    assert rel_err(out, 0.5 * (x.double() @ bf16r(wt).double().t())) < 1e-5
+    assert rel_err(out, 0.5 * (x.double() @ wt.double().t())) < 5e-3
+    if M % 32 == 0:     # per-modality matrices: rows [0, M/2) use wt2[0], the rest wt2[1]
+        wt2 = torch.stack([wt, rnd(R, K, seed=9)])
+        o2 = ops.skinny_nt(x, wt2, rows_per_group=M // 2)
+        ref2 = torch.cat([x[:M // 2].double() @ bf16r(wt2[0]).double().t(), x[M // 2:].double() @ bf16r(wt2[1]).double().t()])
+        assert rel_err(o2, ref2) < 1e-5
     u = rnd(M, R, seed=3)
     for tr in (False, True):
         o = ops.skinny_tn(x, u, transposed=tr, scale=2.0)
         ref = 2.0 * (x.double().t() @ u.double())
         assert rel_err(o, ref.t() if tr else ref) < 1e-4
+        if M % 2 == 0:
+            o2 = ops.skinny_tn(x, u, transposed=tr, scale=2.0, n_groups=2)
+            for g in range(2):
+                sl = slice(g * M // 2, (g + 1) * M // 2)
+                rg = 2.0 * (x[sl].double().t() @ u[sl].double())
+                assert rel_err(o2[g], rg.t() if tr else rg) < 1e-4
 
 
 def test_lora_mix(ops):
