@@ -43,16 +43,15 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((unsigned int)v) << 16);
 }
-// round-to-nearest-even; NaN stays NaN (quiet)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even by the gfx950 conversion instruction (v_cvt_pk_bf16_f32): one VALU op per pair
+// instead of a dozen with a NaN branch
+typedef __attribute__((ext_vector_type(2))) float mf_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 mf_bf16x2_t;
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-  return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+  const mf_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, mf_bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float bf16_lo(unsigned int w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
 
@@ -68,11 +67,27 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // exact (erf) GELU and its derivative, as nn.GELU() default
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// Exact (erf) GELU of nn.GELU, with erfc from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32
+// round-off level): one v_rcp + one v_exp + 7 FMAs instead of the branchy library erff - the GELU epilogues
+// of the MLP GEMMs evaluate it 64 times per lane. cdf(x) = 1 - erfc(x/sqrt2)/2 for x >= 0, erfc(|x|/sqrt2)/2
+// below (no cancellation in the left tail).
+__device__ __forceinline__ float gelu_cdf_pdf(float x, float* pdf) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float pl = fmaf(t, 1.061405429f, -1.453152027f);
+  pl = fmaf(pl, t, 1.421413741f);
+  pl = fmaf(pl, t, -0.284496736f);
+  pl = fmaf(pl, t, 0.254829592f);
+  const float e = __expf(-z * z);           // = exp(-x^2/2)
+  const float hq = 0.5f * pl * t * e;       // erfc(z) / 2
+  *pdf = 0.3989422804014327f * e;
+  return x < 0.f ? hq : 1.0f - hq;
+}
+__device__ __forceinline__ float gelu_f(float x) { float pdf; return x * gelu_cdf_pdf(x, &pdf); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float pdf;
+  const float cdf = gelu_cdf_pdf(x, &pdf);
+  return fmaf(x, pdf, cdf);
 }
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -2,7 +2,8 @@
 //
 //   C[m,n] = sum_k A[m,k] * W[n,k]                       (A: [M,K] bf16, W: [N,K] bf16, fp32 accumulate)
 //          + bias[n]
-//          + lr_scale * sum_{j<R} U[m,j] * V[g(m)][n,j]   (fp32 low-rank update: LoRA fwd / LoRA dgrad)
+//          + lr_scale * sum_{j<R} U[m,j] * V[g(m)][n,j]   (low-rank update: LoRA fwd / LoRA dgrad; fp32 U, V rounded to
+//                                                           bf16 and accumulated by one extra MFMA k-step)
 //          -> act: none | GELU (optionally also stores the pre-activation) | multiply by GELU'(aux[m,n])
 //          + residual[m % res_row_mod, n]                 (fp32; may alias the fp32 output)
 //          -> out (bf16 or fp32)
@@ -47,6 +48,10 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 __device__ __forceinline__ int swz_x(int row) { return row & 7; }
 __device__ __forceinline__ int swz_w(int row) { return (((row >> 4) & 3) << 1) | ((row >> 1) & 1); }
 
+// ACT = GemmParams::act. The activations
+// and low-rank epilogues are compiled into separate instantiations: one kernel with everything is ~100 KB of
+// code, more than the 64 KB instruction cache a CU pair shares.
+template <int ACT, bool LORA>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (BM + BN) * BK * 2];  // 64 KiB
   const int tid = threadIdx.x;
@@ -116,6 +121,50 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+  // ---- epilogue operands that do not depend on the accumulators are requested BEFORE the main loop, so
+  // their latency hides behind it: bias, and the raw fp32 rows of the low-rank factors.
+  // Lane owns rows m(mi) = m0+wm*64+mi*16+fr and columns nb..nb+15 of the output.
+  const int nb = n0 + wn * 64 + 16 * fq;
+  int mrow[4];
+  bool mok[4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    mrow[mi] = m0 + wm * 64 + mi * 16 + fr;
+    mok[mi] = mrow[mi] < p.M;
+  }
+  float4 bias4[4];
+  if (p.bias) {
+    const int nbc = nb < p.N ? nb : p.N - 16;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) bias4[ni] = *reinterpret_cast<const float4*>(p.bias + nbc + 4 * ni);
+  }
+  // Low-rank update = extra MFMA k-steps whose 32 k-slots hold the rank index up to three times:
+  // slots [0,Rp) U_hi.V_hi, [Rp,2Rp) U_lo.V_hi, [2Rp,3Rp) U_hi.V_lo (hi = bf16(x), lo = bf16(x - hi); Rp = 8
+  // for R <= 8 -> one k-step, else 16 -> two), so the fp32 U (x lr_scale) and V keep ~16 mantissa bits
+  // although the product runs on the bf16 matrix cores. Every lane needs the same 8 floats for each slot
+  // group; the modality group is uniform per workgroup (the host splits launches that would straddle).
+  const int R = p.R, Rp = R <= 8 ? 8 : 16;
+  const int lk0 = Rp == 8 ? 0 : 8 * (fq & 1);
+  float4 uraw[4][2], vraw[4][2];
+  if (LORA) {
+    // unconditional loads (a masked-off second half re-reads the first): no branch, no wait between them
+    const int lk1 = lk0 + 4 < R ? lk0 + 4 : lk0;
+    auto load_raw = [&](float4 (&dst)[2], const float* src) {
+      dst[0] = *reinterpret_cast<const float4*>(src + lk0);
+      dst[1] = *reinterpret_cast<const float4*>(src + lk1);
+    };
+    const int g = p.n_groups > 1 ? (int)(((unsigned)m0 / (unsigned)p.rows_per_group) % (unsigned)p.n_groups) : 0;
+    const float* vg = p.V + (int64_t)g * p.v_group_stride;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) load_raw(uraw[mi], p.U + (int64_t)(mok[mi] ? mrow[mi] : p.M - 1) * p.ldu);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      int n = n0 + wn * 64 + 16 * (fr >> 2) + 4 * ni + (fr & 3);      // W-row order of the accumulator tiles
+      n = n < p.N ? n : p.N - 1;
+      load_raw(vraw[ni], vg + (int64_t)n * R);
+    }
+  }
+
   int t_begin = 0, t_end = nt;
   if (p.k_splits > 1) {
     t_begin = (int)((int64_t)nt * blockIdx.y / p.k_splits);
@@ -146,16 +195,39 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     }
   }
 
-  // ---- epilogue: lane owns rows m(mi) = m0+wm*64+mi*16+fr and columns nb..nb+15
-  const int nb = n0 + wn * 64 + 16 * fq;
-  if (nb >= p.N) return;
-  int mrow[4];
-  bool mok[4];
+  // ---- epilogue
+  if (LORA) {
+    // branch-free conversion: `lo` and a zero scale are lane selects
+    auto conv = [&](const float4 (&raw)[2], float sc, bool lo) -> bf16x8_t {
+      const float s1 = lk0 + 4 < R ? sc : 0.f;
+      const float x[8] = {raw[0].x * sc, raw[0].y * sc, raw[0].z * sc, raw[0].w * sc,
+                          raw[1].x * s1, raw[1].y * s1, raw[1].z * s1, raw[1].w * s1};
+      union { bf16x8_t v; unsigned int w[4]; } r;
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    mrow[mi] = m0 + wm * 64 + mi * 16 + fr;
-    mok[mi] = mrow[mi] < p.M;
+      for (int i = 0; i < 4; ++i) {
+        const unsigned int h = pack_bf16x2(x[2 * i], x[2 * i + 1]);
+        const unsigned int l = pack_bf16x2(x[2 * i] - bf16_lo(h), x[2 * i + 1] - bf16_hi(h));
+        r.w[i] = lo ? l : h;
+      }
+      return r.v;
+    };
+    const int npass = Rp == 8 ? 1 : 2;
+    for (int pass = 0; pass < npass; ++pass) {
+      const int comp = Rp == 8 ? fq : 2 * pass + (fq >> 1);      // which product this lane's 8 k-slots belong to
+      const float on = comp <= 2 ? 1.0f : 0.0f;
+      bf16x8_t vf[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) vf[ni] = conv(vraw[ni], on, comp == 2);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const bf16x8_t um = conv(uraw[mi], on * p.lr_scale, comp == 1);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[ni], um, acc[ni][mi], 0, 0, 0);
+      }
+    }
   }
+  if (nb >= p.N) return;
   if (p.k_splits > 1) {      // split-K partial: plain stores into slice blockIdx.y of out [k_splits][M][ldc]
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
@@ -168,111 +240,111 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
   }
   if (p.bias) {
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const float4 b = *reinterpret_cast<const float4*>(p.bias + nb + 4 * ni);
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        acc[ni][mi][0] += b.x; acc[ni][mi][1] += b.y; acc[ni][mi][2] += b.z; acc[ni][mi][3] += b.w;
-      }
-    }
-  }
-  if (p.U) {
-    const int R = p.R;
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      if (!mok[mi]) continue;
-      float u[GEMM_MAX_R];
-      const float* up = p.U + (int64_t)mrow[mi] * p.ldu;
-#pragma unroll
-      for (int j = 0; j < GEMM_MAX_R; j += 4) {
-        if (j < R) {
-          const float4 t4 = *reinterpret_cast<const float4*>(up + j);
-          u[j] = t4.x * p.lr_scale; u[j + 1] = t4.y * p.lr_scale; u[j + 2] = t4.z * p.lr_scale; u[j + 3] = t4.w * p.lr_scale;
-        } else { u[j] = u[j + 1] = u[j + 2] = u[j + 3] = 0.f; }
-      }
-      const int g = p.n_groups > 1 ? (int)((mrow[mi] / p.rows_per_group) % p.n_groups) : 0;
-      const float* vp = p.V + (int64_t)g * p.v_group_stride + (int64_t)nb * R;
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float* vr = vp + (int64_t)(4 * ni + r) * R;
-          float s = 0.f;
-#pragma unroll
-          for (int j = 0; j < GEMM_MAX_R; j += 4) {
-            if (j < R) {
-              const float4 v4 = *reinterpret_cast<const float4*>(vr + j);
-              s += u[j] * v4.x + u[j + 1] * v4.y + u[j + 2] * v4.z + u[j + 3] * v4.w;
-            }
-          }
-          acc[ni][mi][r] += s;
-        }
-    }
-  }
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    if (!mok[mi]) continue;
-    const int64_t m = mrow[mi];
-    float v[16];
-#pragma unroll
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[4 * ni + r] = acc[ni][mi][r];
+      for (int mi = 0; mi < 4; ++mi) {
+        acc[ni][mi][0] += bias4[ni].x; acc[ni][mi][1] += bias4[ni].y; acc[ni][mi][2] += bias4[ni].z; acc[ni][mi][3] += bias4[ni].w;
+      }
+  }
+  // Two row tiles per round: their aux / residual loads are issued together ahead of the stores (which may
+  // alias `residual`), so each kind of operand costs two memory round trips per workgroup instead of four.
+#pragma unroll
+  for (int mh = 0; mh < 4; mh += 2) {
+    int mc[2];
+#pragma unroll
+    for (int mj = 0; mj < 2; ++mj) mc[mj] = mok[mh + mj] ? mrow[mh + mj] : p.M - 1;
     if (p.out_pre) {   // value before activation / residual (GELU pre-activation, adapter input, ...)
-      u32x4_t w0, w1;
-      w0.x = pack_bf16x2(v[0], v[1]); w0.y = pack_bf16x2(v[2], v[3]); w0.z = pack_bf16x2(v[4], v[5]); w0.w = pack_bf16x2(v[6], v[7]);
-      w1.x = pack_bf16x2(v[8], v[9]); w1.y = pack_bf16x2(v[10], v[11]); w1.z = pack_bf16x2(v[12], v[13]); w1.w = pack_bf16x2(v[14], v[15]);
-      u32x4_t* dst = reinterpret_cast<u32x4_t*>(p.out_pre + m * p.ldpre + nb);
-      dst[0] = w0; dst[1] = w1;
+#pragma unroll
+      for (int mj = 0; mj < 2; ++mj) {
+        const int mi = mh + mj;
+        if (!mok[mi]) continue;
+        u32x4_t w0, w1;
+        w0.x = pack_bf16x2(acc[0][mi][0], acc[0][mi][1]); w0.y = pack_bf16x2(acc[0][mi][2], acc[0][mi][3]);
+        w0.z = pack_bf16x2(acc[1][mi][0], acc[1][mi][1]); w0.w = pack_bf16x2(acc[1][mi][2], acc[1][mi][3]);
+        w1.x = pack_bf16x2(acc[2][mi][0], acc[2][mi][1]); w1.y = pack_bf16x2(acc[2][mi][2], acc[2][mi][3]);
+        w1.z = pack_bf16x2(acc[3][mi][0], acc[3][mi][1]); w1.w = pack_bf16x2(acc[3][mi][2], acc[3][mi][3]);
+        u32x4_t* dst = reinterpret_cast<u32x4_t*>(p.out_pre + (int64_t)mrow[mi] * p.ldpre + nb);
+        dst[0] = w0; dst[1] = w1;
+      }
     }
-    if (p.act == 1) {
+    if (ACT == 1) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = gelu_f(v[i]);
-    } else if (p.act == 2 || p.act == 4) {
-      const u32x4_t* ap = reinterpret_cast<const u32x4_t*>(p.aux + m * p.ldaux + nb);
-      const u32x4_t a0 = ap[0], a1 = ap[1];
-      const unsigned int aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-      if (p.act == 2) {
+      for (int mj = 0; mj < 2; ++mj)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          v[2 * i] *= gelu_grad_f(bf16_lo(aw[i]));
-          v[2 * i + 1] *= gelu_grad_f(bf16_hi(aw[i]));
-        }
-      } else {
+        for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+          for (int r = 0; r < 4; ++r) acc[ni][mh + mj][r] = gelu_f(acc[ni][mh + mj][r]);
+    } else if (ACT == 2 || ACT == 4) {
+      u32x4_t ax[2][2];
+#pragma unroll
+      for (int mj = 0; mj < 2; ++mj) {
+        const u32x4_t* ap = reinterpret_cast<const u32x4_t*>(p.aux + (int64_t)mc[mj] * p.ldaux + nb);
+        ax[mj][0] = ap[0]; ax[mj][1] = ap[1];
+      }
+#pragma unroll
+      for (int mj = 0; mj < 2; ++mj) {
+        const int mi = mh + mj;
+        const unsigned int aw[8] = {ax[mj][0].x, ax[mj][0].y, ax[mj][0].z, ax[mj][0].w, ax[mj][1].x, ax[mj][1].y, ax[mj][1].z, ax[mj][1].w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {        // aux words 2*ni, 2*ni+1 cover accumulator tile ni
           const float lo = bf16_lo(aw[i]), hi = bf16_hi(aw[i]);
-          v[2 * i] = (lo > 0.f && lo < 6.f) ? v[2 * i] : 0.f;
-          v[2 * i + 1] = (hi > 0.f && hi < 6.f) ? v[2 * i + 1] : 0.f;
+          float v0 = acc[i >> 1][mi][2 * (i & 1)], v1 = acc[i >> 1][mi][2 * (i & 1) + 1];
+          if (ACT == 2) { v0 *= gelu_grad_f(lo); v1 *= gelu_grad_f(hi); }
+          else { v0 = (lo > 0.f && lo < 6.f) ? v0 : 0.f; v1 = (hi > 0.f && hi < 6.f) ? v1 : 0.f; }
+          acc[i >> 1][mi][2 * (i & 1)] = v0; acc[i >> 1][mi][2 * (i & 1) + 1] = v1;
         }
       }
-    } else if (p.act == 3) {
+    } else if (ACT == 3) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = fminf(fmaxf(v[i], 0.f), 6.f);
+      for (int mj = 0; mj < 2; ++mj)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[ni][mh + mj][r] = fminf(fmaxf(acc[ni][mh + mj][r], 0.f), 6.f);
     }
     if (p.residual) {
-      const int64_t rr = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
-      const float4* rp = reinterpret_cast<const float4*>(p.residual + rr * p.ldres + nb);
+      float4 rs[2][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float4 r4 = rp[i];
-        v[4 * i] += r4.x; v[4 * i + 1] += r4.y; v[4 * i + 2] += r4.z; v[4 * i + 3] += r4.w;
+      for (int mj = 0; mj < 2; ++mj) {
+        const int rr = p.res_row_mod > 0 ? (int)((unsigned)mc[mj] % (unsigned)p.res_row_mod) : mc[mj];
+        const float4* rp = reinterpret_cast<const float4*>(p.residual + (int64_t)rr * p.ldres + nb);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) rs[mj][ni] = rp[ni];
       }
-    }
-    if (p.act == 5) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = fminf(fmaxf(v[i], 0.f), 6.f);
-    }
-    if (p.out_dtype == MFNET_BF16) {
-      u32x4_t w0, w1;
-      w0.x = pack_bf16x2(v[0], v[1]); w0.y = pack_bf16x2(v[2], v[3]); w0.z = pack_bf16x2(v[4], v[5]); w0.w = pack_bf16x2(v[6], v[7]);
-      w1.x = pack_bf16x2(v[8], v[9]); w1.y = pack_bf16x2(v[10], v[11]); w1.z = pack_bf16x2(v[12], v[13]); w1.w = pack_bf16x2(v[14], v[15]);
-      u32x4_t* dst = reinterpret_cast<u32x4_t*>((bf16_t*)p.out + m * p.ldc + nb);
-      dst[0] = w0; dst[1] = w1;
-    } else {
-      float4* dst = reinterpret_cast<float4*>((float*)p.out + m * p.ldc + nb);
+      for (int mj = 0; mj < 2; ++mj)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dst[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+        for (int ni = 0; ni < 4; ++ni) {
+          f32x4_t& a = acc[ni][mh + mj];
+          a[0] += rs[mj][ni].x; a[1] += rs[mj][ni].y; a[2] += rs[mj][ni].z; a[3] += rs[mj][ni].w;
+        }
+    }
+    if (ACT == 5) {
+#pragma unroll
+      for (int mj = 0; mj < 2; ++mj)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[ni][mh + mj][r] = fminf(fmaxf(acc[ni][mh + mj][r], 0.f), 6.f);
+    }
+#pragma unroll
+    for (int mj = 0; mj < 2; ++mj) {
+      const int mi = mh + mj;
+      if (!mok[mi]) continue;
+      const int64_t m = mrow[mi];
+      if (p.out_dtype == MFNET_BF16) {
+        u32x4_t w0, w1;
+        w0.x = pack_bf16x2(acc[0][mi][0], acc[0][mi][1]); w0.y = pack_bf16x2(acc[0][mi][2], acc[0][mi][3]);
+        w0.z = pack_bf16x2(acc[1][mi][0], acc[1][mi][1]); w0.w = pack_bf16x2(acc[1][mi][2], acc[1][mi][3]);
+        w1.x = pack_bf16x2(acc[2][mi][0], acc[2][mi][1]); w1.y = pack_bf16x2(acc[2][mi][2], acc[2][mi][3]);
+        w1.z = pack_bf16x2(acc[3][mi][0], acc[3][mi][1]); w1.w = pack_bf16x2(acc[3][mi][2], acc[3][mi][3]);
+        u32x4_t* dst = reinterpret_cast<u32x4_t*>((bf16_t*)p.out + m * p.ldc + nb);
+        dst[0] = w0; dst[1] = w1;
+      } else {
+        float4* dst = reinterpret_cast<float4*>((float*)p.out + m * p.ldc + nb);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) dst[ni] = make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
+      }
     }
   }
 }
@@ -297,13 +369,30 @@ extern "C" int mfnet_gemm_bf16(const void* A, int64_t lda, const void* W, int64_
   MF_CHECK_ARG(!residual || (ldres >= N && ldres % 4 == 0), "gemm_bf16: bad residual ld");
   if (U) {
     MF_CHECK_ARG(V && R > 0 && R <= GEMM_MAX_R && R % 4 == 0 && ldu >= R && ldu % 4 == 0, "gemm_bf16: bad low-rank args (R=%d)", R);
-    MF_CHECK_ARG(n_groups >= 1 && (n_groups == 1 || rows_per_group > 0), "gemm_bf16: bad group args");
+    MF_CHECK_ARG(n_groups >= 1 && (n_groups == 1 || rows_per_group >= 16), "gemm_bf16: bad group args (rows_per_group must be >= 16)");
   }
   MF_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31), "gemm_bf16: shape too large");
   MF_CHECK_ARG(k_splits >= 1 && k_splits <= 1024, "gemm_bf16: bad k_splits");
   MF_CHECK_ARG(k_splits == 1 || (out_dtype == MFNET_F32 && !bias && !U && act == 0 && !out_pre && !residual),
                "gemm_bf16: split-K supports only the plain fp32 accumulate-into-out epilogue");
   if (M == 0) return MFNET_OK;
+  if (U && n_groups > 1 && rows_per_group % BM != 0) {
+    // The kernel takes the modality group per 128-row tile. Row blocks that do not end on a tile boundary
+    // are launched one by one (never the case for MFNet's 256-pixel tiles: rows_per_group = B * 256).
+    MF_CHECK_ARG(res_row_mod == 0, "gemm_bf16: grouped low-rank update with rows_per_group %% 128 != 0 cannot take res_row_mod");
+    const size_t osz = out_dtype == MFNET_BF16 ? 2 : 4;
+    for (int64_t r0 = 0, b = 0; r0 < M; r0 += rows_per_group, ++b) {
+      const int64_t rows = M - r0 < rows_per_group ? M - r0 : rows_per_group;
+      const int rc = mfnet_gemm_bf16((const char*)A + r0 * lda * 2, lda, W, ldw, rows, N, K, bias, U + r0 * ldu, ldu,
+                                     V + (b % n_groups) * v_group_stride, 0, 0, 1, R, lr_scale, act,
+                                     aux ? (const char*)aux + r0 * ldaux * 2 : nullptr, ldaux,
+                                     out_pre ? (char*)out_pre + r0 * ldpre * 2 : nullptr, ldpre,
+                                     residual ? residual + r0 * ldres : nullptr, ldres, 0,
+                                     (char*)out + r0 * ldc * osz, out_dtype, ldc, 1, stream);
+      if (rc) return rc;
+    }
+    return MFNET_OK;
+  }
   GemmParams p;
   p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.bias = bias;
@@ -316,7 +405,12 @@ extern "C" int mfnet_gemm_bf16(const void* A, int64_t lda, const void* W, int64_
   const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
   MF_CHECK_ARG(nwg < (1ll << 31), "gemm_bf16: too many tiles");
   p.k_splits = k_splits;
-  hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)nwg, (unsigned)k_splits), dim3(256), 0, stream, p);
+  const dim3 grid((unsigned)nwg, (unsigned)k_splits);
+#define MF_GEMM_LAUNCH(A_, L_) hipLaunchKernelGGL((gemm_bf16_kernel<A_, L_>), grid, dim3(256), 0, stream, p)
+#define MF_GEMM_CASE(A_) case A_: if (U) MF_GEMM_LAUNCH(A_, true); else MF_GEMM_LAUNCH(A_, false); break;
+  switch (act) { MF_GEMM_CASE(0) MF_GEMM_CASE(1) MF_GEMM_CASE(2) MF_GEMM_CASE(3) MF_GEMM_CASE(4) MF_GEMM_CASE(5) }
+#undef MF_GEMM_CASE
+#undef MF_GEMM_LAUNCH
   MF_LAUNCH_CHECK("gemm_bf16");
   return MFNET_OK;
 }
