@@ -55,15 +55,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdParams p) {
   }
   // ---- T^T = tbl . Q^T  -> T_lds[query][table row]
   float* Trow = T_lds + (wave * 16 + fr) * TLD;
-  for (int t = 0; t < g.NT / 16; ++t) {
-    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const bf16_t* tp = p.tbl + (int64_t)(16 * t + fr) * ATT_HD + 8 * fq;
-    const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(tp);
-    const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(tp + 32);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[1], acc, 0, 0, 0);
-    *reinterpret_cast<float4*>(Trow + 16 * t + 4 * fq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-  }
+  att_table_product(p.tbl, g.NT, qf, Trow, fr, fq);
   const int qoff_h = qp.qh, qoff_w = qp.qw;
 
   float m_run = -INFINITY, l_run = 0.f;
@@ -71,35 +63,41 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdParams p) {
 #pragma unroll
   for (int u = 0; u < 4; ++u) o[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+  // this thread always stages 16-B chunk `ch` of a key row: the padded-key value of that chunk (the qkv bias,
+  // rounded to bf16 like every other qkv entry) is kept in registers
+  const int ch = tid & 7;
+  const PaddedKV pad = att_padded_kv(p.qkv_bias, g.D, head, ch);
+
   for (int kc = 0; kc < Nk; kc += ATT_KC) {
-    __syncthreads();   // previous chunk fully consumed (also orders T_lds writes on the first pass)
-    // ---- stage K (row-major, swizzled), V^T and the per-key bias indices
-    for (int it = 0; it < (ATT_KC * 8) / 256; ++it) {
-      const int kl = it * 32 + (tid >> 3), ch = tid & 7;
-      const int kg = kc + kl;
-      u32x4_t kv = (u32x4_t){0u, 0u, 0u, 0u}, vv = kv;
+    // ---- stage K (row-major, swizzled), V^T and the per-key bias indices. All global loads of the chunk
+    // are issued first, unconditionally (padded / out-of-range keys read row 0 and are replaced afterwards):
+    // one memory round trip per chunk, overlapping the other waves' tail of the previous chunk.
+    u32x4_t kv[ATT_KC / 32], vv[ATT_KC / 32];
+    int kmeta[ATT_KC / 32];
+#pragma unroll
+    for (int it = 0; it < ATT_KC / 32; ++it) {
+      const int kg = kc + it * 32 + (tid >> 3);
       int kh = 0, kw = 0;
-      if (kg < Nk) {
-        const int tok = key_token(g, wi, wj, kg, &kh, &kw);
-        if (tok >= 0) {
-          const bf16_t* src = p.qkv + (row_base + tok) * ld + g.D + head * ATT_HD + ch * 8;
-          kv = *reinterpret_cast<const u32x4_t*>(src);
-          vv = *reinterpret_cast<const u32x4_t*>(src + g.D);
-        } else {
-          const float* bk = p.qkv_bias + g.D + head * ATT_HD + ch * 8;
-          const float4 a = *reinterpret_cast<const float4*>(bk), b = *reinterpret_cast<const float4*>(bk + 4);
-          const float4 c = *reinterpret_cast<const float4*>(bk + g.D), d = *reinterpret_cast<const float4*>(bk + g.D + 4);
-          kv.x = pack_bf16x2(a.x, a.y); kv.y = pack_bf16x2(a.z, a.w); kv.z = pack_bf16x2(b.x, b.y); kv.w = pack_bf16x2(b.z, b.w);
-          vv.x = pack_bf16x2(c.x, c.y); vv.y = pack_bf16x2(c.z, c.w); vv.z = pack_bf16x2(d.x, d.y); vv.w = pack_bf16x2(d.z, d.w);
-        }
-      }
-      *reinterpret_cast<u32x4_t*>(K_lds + kl * 128 + ((ch ^ kswz(kl)) << 4)) = kv;
+      const int tok = kg < Nk ? key_token(g, wi, wj, kg, &kh, &kw) : -2;
+      const bf16_t* src = p.qkv + (row_base + max(tok, 0)) * ld + g.D + head * ATT_HD + ch * 8;
+      kv[it] = *reinterpret_cast<const u32x4_t*>(src);
+      vv[it] = *reinterpret_cast<const u32x4_t*>(src + g.D);
+      kmeta[it] = (tok < 0 ? (tok == -2 ? 2 : 1) : 0) | (((g.KH - 1 - kh) | ((g.Lh + g.KW - 1 - kw) << 16)) << 2);
+    }
+    __syncthreads();   // previous chunk fully consumed (also orders T_lds writes on the first pass)
+#pragma unroll
+    for (int it = 0; it < ATT_KC / 32; ++it) {
+      const int kl = it * 32 + (tid >> 3);
+      const int kind = kmeta[it] & 3;          // 0 real, 1 padded, 2 beyond the window
+      u32x4_t k4 = kind == 0 ? kv[it] : pad.k, v4 = kind == 0 ? vv[it] : pad.v;
+      if (kind == 2) { k4 = (u32x4_t){0u, 0u, 0u, 0u}; v4 = k4; }
+      *reinterpret_cast<u32x4_t*>(K_lds + kl * 128 + ((ch ^ kswz(kl)) << 4)) = k4;
       bf16_t* vt = Vt_lds + (ch * 8) * ATT_VT_LD + kl;
-      vt[0 * ATT_VT_LD] = (bf16_t)(vv.x & 0xffff); vt[1 * ATT_VT_LD] = (bf16_t)(vv.x >> 16);
-      vt[2 * ATT_VT_LD] = (bf16_t)(vv.y & 0xffff); vt[3 * ATT_VT_LD] = (bf16_t)(vv.y >> 16);
-      vt[4 * ATT_VT_LD] = (bf16_t)(vv.z & 0xffff); vt[5 * ATT_VT_LD] = (bf16_t)(vv.z >> 16);
-      vt[6 * ATT_VT_LD] = (bf16_t)(vv.w & 0xffff); vt[7 * ATT_VT_LD] = (bf16_t)(vv.w >> 16);
-      if (ch == 0) kidx_lds[kl] = (g.KH - 1 - kh) | ((g.Lh + g.KW - 1 - kw) << 16);
+      vt[0 * ATT_VT_LD] = (bf16_t)(v4.x & 0xffff); vt[1 * ATT_VT_LD] = (bf16_t)(v4.x >> 16);
+      vt[2 * ATT_VT_LD] = (bf16_t)(v4.y & 0xffff); vt[3 * ATT_VT_LD] = (bf16_t)(v4.y >> 16);
+      vt[4 * ATT_VT_LD] = (bf16_t)(v4.z & 0xffff); vt[5 * ATT_VT_LD] = (bf16_t)(v4.z >> 16);
+      vt[6 * ATT_VT_LD] = (bf16_t)(v4.w & 0xffff); vt[7 * ATT_VT_LD] = (bf16_t)(v4.w >> 16);
+      if (ch == 0) kidx_lds[kl] = kmeta[it] >> 2;
     }
     __syncthreads();
     const int kvalid = min(ATT_KC, Nk - kc);

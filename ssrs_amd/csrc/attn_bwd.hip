@@ -83,50 +83,47 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
   // T^T = tbl . Q^T -> T_lds
   float* Trow = T_lds + (wave * 16 + fr) * TLD;
   float* dTrow = dT_lds + (wave * 16 + fr) * TLD;
-  for (int t = 0; t < g.NT / 16; ++t) {
-    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const bf16_t* tp = p.tbl + (int64_t)(16 * t + fr) * ATT_HD + 8 * fq;
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(tp), qf[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(tp + 32), qf[1], acc, 0, 0, 0);
-    *reinterpret_cast<float4*>(Trow + 16 * t + 4 * fq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-  }
+  att_table_product(p.tbl, g.NT, qf, Trow, fr, fq);
 
   f32x4_t dq[4], dgt[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) { dq[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dgt[u] = dq[u]; }
 
+  const int ch = tid & 7;          // this thread always stages 16-B chunk `ch` of a key row
+  const PaddedKV pad = att_padded_kv(p.qkv_bias, g.D, head, ch);
+
   for (int kc = 0; kc < Nk; kc += ATT_KC) {
-    __syncthreads();
-    for (int it = 0; it < (ATT_KC * 8) / 256; ++it) {
-      const int kl = it * 32 + (tid >> 3), ch = tid & 7;
-      const int kg = kc + kl;
-      u32x4_t kv = (u32x4_t){0u, 0u, 0u, 0u}, vv = kv;
+    // all global loads of the chunk first, unconditionally (see attn_fwd_kernel)
+    u32x4_t kv[ATT_KC / 32], vv[ATT_KC / 32];
+    int kmeta[ATT_KC / 32];
+#pragma unroll
+    for (int it = 0; it < ATT_KC / 32; ++it) {
+      const int kg = kc + it * 32 + (tid >> 3);
       int kh = 0, kw = 0;
-      if (kg < Nk) {
-        const int tok = key_token(g, wi, wj, kg, &kh, &kw);
-        if (tok >= 0) {
-          const bf16_t* src = p.qkv + (row_base + tok) * ld + g.D + head * ATT_HD + ch * 8;
-          kv = *reinterpret_cast<const u32x4_t*>(src);
-          vv = *reinterpret_cast<const u32x4_t*>(src + g.D);
-        } else {
-          const float* bk = p.qkv_bias + g.D + head * ATT_HD + ch * 8;
-          const float4 a = *reinterpret_cast<const float4*>(bk), b = *reinterpret_cast<const float4*>(bk + 4);
-          const float4 c = *reinterpret_cast<const float4*>(bk + g.D), d = *reinterpret_cast<const float4*>(bk + g.D + 4);
-          kv.x = pack_bf16x2(a.x, a.y); kv.y = pack_bf16x2(a.z, a.w); kv.z = pack_bf16x2(b.x, b.y); kv.w = pack_bf16x2(b.z, b.w);
-          vv.x = pack_bf16x2(c.x, c.y); vv.y = pack_bf16x2(c.z, c.w); vv.z = pack_bf16x2(d.x, d.y); vv.w = pack_bf16x2(d.z, d.w);
-        }
-      }
-      *reinterpret_cast<u32x4_t*>(K_lds + kl * 128 + ((ch ^ kswz(kl)) << 4)) = kv;
-      *reinterpret_cast<u32x4_t*>(V_lds + kl * 128 + ((ch ^ kswz(kl)) << 4)) = vv;
+      const int tok = kg < Nk ? key_token(g, wi, wj, kg, &kh, &kw) : -2;
+      const bf16_t* src = p.qkv + (row_base + max(tok, 0)) * ld + g.D + head * ATT_HD + ch * 8;
+      kv[it] = *reinterpret_cast<const u32x4_t*>(src);
+      vv[it] = *reinterpret_cast<const u32x4_t*>(src + g.D);
+      kmeta[it] = (tok < 0 ? (tok == -2 ? 2 : 1) : 0) | (kh << 2) | (kw << 10);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ATT_KC / 32; ++it) {
+      const int kl = it * 32 + (tid >> 3);
+      const int kind = kmeta[it] & 3, kh = (kmeta[it] >> 2) & 0xff, kw = (kmeta[it] >> 10) & 0xff;
+      u32x4_t k4 = kind == 0 ? kv[it] : pad.k, v4 = kind == 0 ? vv[it] : pad.v;
+      if (kind == 2) { k4 = (u32x4_t){0u, 0u, 0u, 0u}; v4 = k4; }
+      *reinterpret_cast<u32x4_t*>(K_lds + kl * 128 + ((ch ^ kswz(kl)) << 4)) = k4;
+      *reinterpret_cast<u32x4_t*>(V_lds + kl * 128 + ((ch ^ kswz(kl)) << 4)) = v4;
       bf16_t* kt_ = Kt_lds + (ch * 8) * ATT_VT_LD + kl;
-      kt_[0 * ATT_VT_LD] = (bf16_t)(kv.x & 0xffff); kt_[1 * ATT_VT_LD] = (bf16_t)(kv.x >> 16);
-      kt_[2 * ATT_VT_LD] = (bf16_t)(kv.y & 0xffff); kt_[3 * ATT_VT_LD] = (bf16_t)(kv.y >> 16);
-      kt_[4 * ATT_VT_LD] = (bf16_t)(kv.z & 0xffff); kt_[5 * ATT_VT_LD] = (bf16_t)(kv.z >> 16);
-      kt_[6 * ATT_VT_LD] = (bf16_t)(kv.w & 0xffff); kt_[7 * ATT_VT_LD] = (bf16_t)(kv.w >> 16);
+      kt_[0 * ATT_VT_LD] = (bf16_t)(k4.x & 0xffff); kt_[1 * ATT_VT_LD] = (bf16_t)(k4.x >> 16);
+      kt_[2 * ATT_VT_LD] = (bf16_t)(k4.y & 0xffff); kt_[3 * ATT_VT_LD] = (bf16_t)(k4.y >> 16);
+      kt_[4 * ATT_VT_LD] = (bf16_t)(k4.z & 0xffff); kt_[5 * ATT_VT_LD] = (bf16_t)(k4.z >> 16);
+      kt_[6 * ATT_VT_LD] = (bf16_t)(k4.w & 0xffff); kt_[7 * ATT_VT_LD] = (bf16_t)(k4.w >> 16);
       if (ch == 0) kidx_lds[kl] = (g.KH - 1 - kh) | ((g.Lh + g.KW - 1 - kw) << 16);
       // indicator rows: thread (kl, ch) fills rows ch, ch+8, ... of column kl
       const int jh = g.KH - 1 - kh, jw = g.KH + g.KW - 1 - kw;
-      const bool kin = kg < Nk;
+      const bool kin = kind != 2;
       for (int j = ch; j < 16 * nG; j += 8) Gt_lds[j * ATT_VT_LD + kl] = (kin && (j == jh || j == jw)) ? (bf16_t)0x3f80 : (bf16_t)0;
     }
     __syncthreads();
@@ -275,22 +272,33 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
   for (int u = 0; u < 4; ++u) { dk[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[u] = dk[u]; }
 
   for (int qc = 0; qc < nq; qc += ATT_QT) {
-    __syncthreads();
-    // ---- stage Q / dO (row-major + transposed), lse, delta, query coordinates
+    // ---- stage Q / dO (row-major + transposed), lse, delta, query coordinates. All global loads first and
+    // unconditional (an invalid query reads the window's first token and is zeroed): one round trip.
+    const int ch = tid & 7;
+    u32x4_t qv[2], dv_[2], ov[2];
+    float lsev[2];
+    int qmeta[2];
+#pragma unroll
     for (int it = 0; it < 2; ++it) {
-      const int ql = it * 32 + (tid >> 3), ch = tid & 7;
-      const QueryPos qq = query_pos(g, wi, wj, qc + ql);
-      u32x4_t qv = (u32x4_t){0u, 0u, 0u, 0u}, dv_ = qv, ov = qv;
-      if (qq.valid) {
-        qv = *reinterpret_cast<const u32x4_t*>(p.qkv + (row_base + qq.tok) * ld + head * ATT_HD + ch * 8);
-        dv_ = *reinterpret_cast<const u32x4_t*>(p.dout + (row_base + qq.tok) * g.D + head * ATT_HD + ch * 8);
-        ov = *reinterpret_cast<const u32x4_t*>(p.out + (row_base + qq.tok) * g.D + head * ATT_HD + ch * 8);
-      }
-      *reinterpret_cast<u32x4_t*>(Q_lds + ql * 128 + ((ch ^ kswz(ql)) << 4)) = qv;
-      *reinterpret_cast<u32x4_t*>(dO_lds + ql * 128 + ((ch ^ kswz(ql)) << 4)) = dv_;
+      const QueryPos qq = query_pos(g, wi, wj, qc + it * 32 + (tid >> 3));
+      qv[it] = *reinterpret_cast<const u32x4_t*>(p.qkv + (row_base + qq.tok) * ld + head * ATT_HD + ch * 8);
+      dv_[it] = *reinterpret_cast<const u32x4_t*>(p.dout + (row_base + qq.tok) * g.D + head * ATT_HD + ch * 8);
+      ov[it] = *reinterpret_cast<const u32x4_t*>(p.out + (row_base + qq.tok) * g.D + head * ATT_HD + ch * 8);
+      lsev[it] = p.lse[((int64_t)gi * g.heads + head) * T + qq.tok];
+      qmeta[it] = qq.qh | (qq.qw << 8) | (qq.valid << 16);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int ql = it * 32 + (tid >> 3);
+      const bool valid = (qmeta[it] >> 16) & 1;
+      if (!valid) { qv[it] = (u32x4_t){0u, 0u, 0u, 0u}; dv_[it] = qv[it]; ov[it] = qv[it]; }
+      *reinterpret_cast<u32x4_t*>(Q_lds + ql * 128 + ((ch ^ kswz(ql)) << 4)) = qv[it];
+      *reinterpret_cast<u32x4_t*>(dO_lds + ql * 128 + ((ch ^ kswz(ql)) << 4)) = dv_[it];
       bf16_t* a = Qt_lds + (ch * 8) * QT_LD + ql;
       bf16_t* b = dOt_lds + (ch * 8) * QT_LD + ql;
-      const unsigned int qw_[4] = {qv.x, qv.y, qv.z, qv.w}, dw_[4] = {dv_.x, dv_.y, dv_.z, dv_.w}, ow_[4] = {ov.x, ov.y, ov.z, ov.w};
+      const unsigned int qw_[4] = {qv[it].x, qv[it].y, qv[it].z, qv[it].w}, dw_[4] = {dv_[it].x, dv_[it].y, dv_[it].z, dv_[it].w},
+                         ow_[4] = {ov[it].x, ov[it].y, ov[it].z, ov[it].w};
       float dl = 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -301,27 +309,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
       dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64); dl += __shfl_xor(dl, 4, 64);
       if (ch == 0) {
         delta_lds[ql] = dl;
-        lse_lds[ql] = qq.valid ? p.lse[((int64_t)gi * g.heads + head) * T + qq.tok] : 0.f;
-        qpos_lds[ql] = qq.qh | (qq.qw << 8) | (qq.valid << 16);
+        lse_lds[ql] = valid ? lsev[it] : 0.f;
+        qpos_lds[ql] = qmeta[it];
       }
     }
     // ---- T^T = tbl . Q^T for this wave's 16 queries of the chunk -> T_lds[query][row]
     {
       const QueryPos qq = query_pos(g, wi, wj, qc + wave * 16 + fr);
-      bf16x8_t qf0 = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}, qf1 = qf0;
-      if (qq.valid) {
-        const bf16_t* qptr = p.qkv + (row_base + qq.tok) * ld + head * ATT_HD + 8 * fq;
-        qf0 = *reinterpret_cast<const bf16x8_t*>(qptr);
-        qf1 = *reinterpret_cast<const bf16x8_t*>(qptr + 32);
-      }
+      const bf16_t* qptr = p.qkv + (row_base + qq.tok) * ld + head * ATT_HD + 8 * fq;
+      bf16x8_t qf0 = *reinterpret_cast<const bf16x8_t*>(qptr), qf1 = *reinterpret_cast<const bf16x8_t*>(qptr + 32);
+      if (!qq.valid) { qf0 = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}; qf1 = qf0; }
       float* Trow = T_lds + (wave * 16 + fr) * TLD;
-      for (int t = 0; t < g.NT / 16; ++t) {
-        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        const bf16_t* tp = p.tbl + (int64_t)(16 * t + fr) * ATT_HD + 8 * fq;
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(tp), qf0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(tp + 32), qf1, acc, 0, 0, 0);
-        *reinterpret_cast<float4*>(Trow + 16 * t + 4 * fq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-      }
+      const bf16x8_t qfx[2] = {qf0, qf1};
+      att_table_product(p.tbl, g.NT, qfx, Trow, fr, fq);
     }
     __syncthreads();
     const int qvalid = min(ATT_QT, nq - qc);

@@ -56,3 +56,44 @@ __device__ __forceinline__ int key_token(const AttnGeom& g, int wi, int wj, int 
 }
 
 __device__ __forceinline__ int kswz(int row) { return row & 7; }   // 16-B chunk XOR for [row][64 hd] images
+
+// ---- shared device helpers of the forward / backward kernels ------------------------------------------
+
+// T^T = tbl . Q^T for this wave's 16 queries -> Trow[table row] (this lane's query). All table loads are
+// issued before the first MFMA (rows beyond NT re-read the last tile), so the product costs one memory
+// round trip instead of NT/16.
+#define ATT_MAX_NT16 16
+__device__ __forceinline__ void att_table_product(const bf16_t* tbl, int NT, const bf16x8_t (&qf)[2], float* Trow, int fr, int fq) {
+  const int nt16 = NT >> 4;
+  for (int t0 = 0; t0 < nt16; t0 += 6) {
+    bf16x8_t a0[6], a1[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int t = min(t0 + i, nt16 - 1);
+      const bf16_t* tp = tbl + (int64_t)(16 * t + fr) * ATT_HD + 8 * fq;
+      a0[i] = *reinterpret_cast<const bf16x8_t*>(tp);
+      a1[i] = *reinterpret_cast<const bf16x8_t*>(tp + 32);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if (t0 + i < nt16) {
+        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], qf[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], qf[1], acc, 0, 0, 0);
+        *reinterpret_cast<float4*>(Trow + 16 * (t0 + i) + 4 * fq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      }
+    }
+  }
+}
+
+// 16-B chunk `ch` of a padded key's K and V rows: the qkv bias (fp32) rounded to bf16
+struct PaddedKV { u32x4_t k, v; };
+__device__ __forceinline__ PaddedKV att_padded_kv(const float* qkv_bias, int D, int head, int ch) {
+  const float* bk = qkv_bias + D + head * ATT_HD + ch * 8;
+  const float4 a = *reinterpret_cast<const float4*>(bk), b = *reinterpret_cast<const float4*>(bk + 4);
+  const float4 c = *reinterpret_cast<const float4*>(bk + D), d = *reinterpret_cast<const float4*>(bk + D + 4);
+  PaddedKV r;
+  r.k.x = pack_bf16x2(a.x, a.y); r.k.y = pack_bf16x2(a.z, a.w); r.k.z = pack_bf16x2(b.x, b.y); r.k.w = pack_bf16x2(b.z, b.w);
+  r.v.x = pack_bf16x2(c.x, c.y); r.v.y = pack_bf16x2(c.z, c.w); r.v.z = pack_bf16x2(d.x, d.y); r.v.w = pack_bf16x2(d.z, d.w);
+  return r;
+}
