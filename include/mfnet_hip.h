@@ -129,6 +129,14 @@ int mfnet_transpose_bf16(const void* x, int64_t ld, void* y, int64_t M, int64_t 
 /* out[i] (= | +=) scale * sum_s partial[s*n + i], n % 4 == 0: second stage of the split-K weight gradients. */
 int mfnet_reduce_splits(const float* partial, float* out, int64_t n, int splits, float scale, int accumulate, hipStream_t stream);
 
+/* Strided gather of n small fp32 tensors in one launch (per 48 segments). desc is a HOST array of n x 14
+ * int64: {src device ptr, dst device ptr, dims[4], src strides[4], dst strides[4]} with strides in elements;
+ * dst_dtype MFNET_F32 (assign, or += when accumulate != 0) or MFNET_BF16 (assign). Replaces the framework
+ * copies the reference's step performs implicitly: weight casts / permutes ahead of every conv and linear
+ * (unetformer_mmsam.py:43-84 Conv/ConvBN/ConvTranspose modules, loralib/layers.py:149-165 B@A products) and
+ * autograd's per-parameter gradient accumulation (trainer.py:160 loss.backward()). */
+int mfnet_gather_segments(const int64_t* desc, int n, int dst_dtype, int accumulate, hipStream_t stream);
+
 /* ---- MMAdapter glue (adapter_fusionblock.py:104-108): out = h + w*ada_own + (1-w)*ada_other per modality
  * (rows [0,M/2) RGB, [M/2,M) DSM); backward gives d ada (bf16) and ADDS (d wx_Adapter, d wy_Adapter) into
  * dw[2]. gelu_fwd/bwd: exact GELU; add_bf16: elementwise sum; bias_grad: out[n] += sum_m dy[m,n]. */

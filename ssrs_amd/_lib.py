@@ -58,6 +58,7 @@ _SIGS = {
     "mfnet_bias_grad": [P, I64, P, I64, I64, P],
     "mfnet_transpose_bf16": [P, I64, P, I64, I64, I64, P],
     "mfnet_reduce_splits": [P, P, I64, I, F, I, P],
+    "mfnet_gather_segments": [P, I, I, I, P],
     # ---- FPN / SE-fusion / UNetFormer decoder (csrc/decoder.hip)
     "mfnet_colsum": [P, I, P, P, I64, I64, I64, P],
     "mfnet_coldot": [P, I, P, I, P, I64, I64, I64, P],

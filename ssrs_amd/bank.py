@@ -1,0 +1,104 @@
+"""Per-step operands derived from TRAINABLE weights, and direct delivery of parameter gradients.
+
+Both exist to keep the train step free of the ~700 tiny framework launches (casts, permuted copies, stacks,
+`cat`s, and autograd's per-parameter `grad += g`) that the reference's step performs implicitly
+(trainer.py:146-197 around unetformer_mmsam.py / loralib modules). Neither changes any arithmetic.
+
+ParamBank - the engine owns one. While it is active (inside TrainEngine.forward_backward), `derived(key, ...)`
+returns a persistent tensor that `ParamBank.refresh()` re-fills from the current parameter values in a few
+`mfnet_gather_segments` launches at the start of every step (inside the captured HIP graph in graph mode).
+The first time a key is seen it is built on the spot and registered. Without an active bank (plain module
+calls, evaluation between steps, autograd tests) every call builds a fresh tensor, so stale weights are
+impossible.
+
+deliver - a parameter the engine adopted carries `_mfnet_sink = (grad_view, notify)`: its gradient, in
+whatever strided layout the kernels produced it, is added into the flat gradient buffer by the same gather
+kernel (one launch per module backward) and autograd receives None for it. Other parameters get an ordinary
+gradient tensor back.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+
+Pair = Tuple[torch.Tensor, torch.Tensor]
+
+
+class ParamBank:
+    active: Optional["ParamBank"] = None
+
+    def __init__(self):
+        self.entries = {}
+
+    def refresh(self):
+        by_dtype = {}
+        for _, pairs in self.entries.values():
+            for d, s in pairs:
+                by_dtype.setdefault(d.dtype, []).append((d, s))
+        for pairs in by_dtype.values():
+            ops.gather(pairs)
+
+    def __enter__(self):
+        ParamBank.active = self
+        self.refresh()
+        return self
+
+    def __exit__(self, *exc):
+        ParamBank.active = None
+        return False
+
+
+def derived(key, shape, dtype, fill: Callable[[torch.Tensor], List[Pair]], device=None) -> torch.Tensor:
+    """Tensor of `shape` whose content is described by `fill(t) -> [(view of t, fp32 source view)]`; parts of
+    t no pair covers stay zero. `key` must identify the sources (use their data_ptr()s) and the recipe."""
+    bank = ParamBank.active
+    if bank is not None:
+        hit = bank.entries.get(key)
+        if hit is not None:
+            return hit[0]
+    t = torch.zeros(shape, dtype=dtype, device=device)
+    with torch.no_grad():
+        pairs = fill(t)
+        ops.gather(pairs)
+    if bank is not None:
+        bank.entries[key] = (t, pairs)
+    return t
+
+
+def weight_bf16(W2d: torch.Tensor, kind="w") -> torch.Tensor:
+    """bf16 GEMM image of a strided fp32 view of a trainable weight (<=4-D; e.g. w.view(O, I).t())."""
+    W2d = W2d.detach()
+    key = (kind, W2d.data_ptr(), tuple(W2d.shape), tuple(W2d.stride()))
+    return derived(key, tuple(W2d.shape), torch.bfloat16, lambda t: [(t, W2d)], device=W2d.device)
+
+
+def deliver(params: Sequence[torch.Tensor], grads: Sequence) -> tuple:
+    """-> the gradient tuple to return to autograd for `params`. grads[i] is None, a tensor view shaped like
+    params[i] (any strides), or a list of (row_slice, tensor) pieces that tile params[i] along dim 0."""
+    out, pairs, notes = [], [], []
+    for p, g in zip(params, grads):
+        sink = getattr(p, "_mfnet_sink", None)
+        if g is None:
+            out.append(None)
+        elif sink is not None:
+            view, notify = sink
+            if isinstance(g, list):
+                for sl, piece in g:
+                    pairs.append((view[sl], piece))
+            else:
+                pairs.append((view, g.view(p.shape) if g.shape != p.shape else g))
+            if notify is not None:
+                notes.append((notify, p))
+            out.append(None)
+        elif isinstance(g, list):
+            out.append(torch.cat([piece for _, piece in g], 0).view(p.shape))
+        else:
+            out.append(g.reshape(p.shape).contiguous())
+    if pairs:
+        ops.gather(pairs, accumulate=True)
+        for notify, p in notes:
+            notify(p)
+    return tuple(out)

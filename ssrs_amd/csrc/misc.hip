@@ -243,3 +243,66 @@ extern "C" int mfnet_reduce_splits(const float* partial, float* out, int64_t n, 
   MF_LAUNCH_CHECK("reduce_splits");
   return MFNET_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Strided gather of many small fp32 tensors in one launch. Each segment copies a logical <=4-D fp32 tensor
+// with arbitrary element strides into another (fp32 assign / fp32 accumulate / bf16 assign). The train step
+// uses it (a) once per step for every operand derived from trainable weights (bf16 GEMM images of the
+// decoder weights in both layouts, the stacked / transposed LoRA factors), and (b) at the end of each
+// module's backward to add the parameter gradients, in whatever layout the kernels produced them, into the
+// flat gradient buffer - instead of ~700 framework copy / cat / add launches per step.
+#define SEG_MAX 48
+struct GatherSeg { const float* src; void* dst; int dims[4]; int sstr[4]; int dstr[4]; };   // 64 bytes
+struct GatherParams { GatherSeg seg[SEG_MAX]; };
+
+__global__ __launch_bounds__(256) void gather_segments_kernel(const GatherParams p, int mode) {
+  const GatherSeg& s = p.seg[blockIdx.y];
+  const unsigned d1 = s.dims[1], d2 = s.dims[2], d3 = s.dims[3];
+  const unsigned n = (unsigned)s.dims[0] * d1 * d2 * d3;
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    unsigned t = i / d3;
+    const unsigned i3 = i - t * d3;
+    unsigned u = t / d2;
+    const unsigned i2 = t - u * d2;
+    const unsigned i0 = u / d1;
+    const unsigned i1 = u - i0 * d1;
+    const int64_t so = (int64_t)i0 * s.sstr[0] + (int64_t)i1 * s.sstr[1] + (int64_t)i2 * s.sstr[2] + (int64_t)i3 * s.sstr[3];
+    const int64_t dofs = (int64_t)i0 * s.dstr[0] + (int64_t)i1 * s.dstr[1] + (int64_t)i2 * s.dstr[2] + (int64_t)i3 * s.dstr[3];
+    const float v = s.src[so];
+    if (mode == 2) ((bf16_t*)s.dst)[dofs] = f32_to_bf16(v);
+    else if (mode == 1) ((float*)s.dst)[dofs] += v;
+    else ((float*)s.dst)[dofs] = v;
+  }
+}
+
+// desc: HOST array of n x 14 int64: {src ptr, dst ptr, dims[4], src strides[4], dst strides[4]} (strides in elements)
+extern "C" int mfnet_gather_segments(const int64_t* desc, int n, int dst_dtype, int accumulate, hipStream_t stream) {
+  MF_CHECK_ARG(n >= 0 && (n == 0 || desc), "gather_segments: bad args");
+  MF_CHECK_ARG(dst_dtype == MFNET_F32 || (dst_dtype == MFNET_BF16 && !accumulate), "gather_segments: accumulate needs an fp32 destination");
+  const int mode = dst_dtype == MFNET_BF16 ? 2 : (accumulate ? 1 : 0);
+  for (int base = 0; base < n; base += SEG_MAX) {
+    const int cnt = n - base < SEG_MAX ? n - base : SEG_MAX;
+    GatherParams p;
+    int64_t nmax = 0;
+    for (int i = 0; i < SEG_MAX; ++i) {
+      const int64_t* d = desc + (int64_t)(base + (i < cnt ? i : 0)) * 14;      // unused slots repeat a valid one
+      GatherSeg& s = p.seg[i];
+      s.src = (const float*)(uintptr_t)d[0]; s.dst = (void*)(uintptr_t)d[1];
+      MF_CHECK_ARG(s.src && s.dst, "gather_segments: null pointer in segment %d", base + i);
+      int64_t tot = 1;
+      for (int k = 0; k < 4; ++k) {
+        MF_CHECK_ARG(d[2 + k] >= 1 && d[2 + k] < (1ll << 31), "gather_segments: bad dim in segment %d", base + i);
+        MF_CHECK_ARG(d[6 + k] >= 0 && d[6 + k] < (1ll << 31) && d[10 + k] >= 0 && d[10 + k] < (1ll << 31), "gather_segments: stride out of range in segment %d", base + i);
+        s.dims[k] = (int)d[2 + k]; s.sstr[k] = (int)d[6 + k]; s.dstr[k] = (int)d[10 + k];
+        tot *= d[2 + k];
+      }
+      MF_CHECK_ARG(tot < (1ll << 31), "gather_segments: segment %d too large", base + i);
+      if (i < cnt && tot > nmax) nmax = tot;
+    }
+    int64_t gx = ceil_div64(nmax, 256 * 8);
+    gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+    hipLaunchKernelGGL(gather_segments_kernel, dim3((unsigned)gx, (unsigned)cnt), dim3(256), 0, stream, p, mode);
+    MF_LAUNCH_CHECK("gather_segments");
+  }
+  return MFNET_OK;
+}

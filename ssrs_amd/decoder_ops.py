@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .bank import deliver, derived, weight_bf16
 from .ops import ACT_GELU, ACT_NONE, ACT_RELU6
 
 BF = torch.bfloat16
@@ -27,18 +28,30 @@ F32 = torch.float32
 
 # ---------------------------------------------------------------------------------------------- helpers
 def _wb(w2d: torch.Tensor) -> torch.Tensor:
-    """bf16 copy of a trainable [N, K] weight (rebuilt every step: it changes every step)."""
-    w2d = w2d.detach().contiguous()
-    return ops.cast(w2d, BF) if w2d.numel() % 8 == 0 else w2d.to(BF)
+    """bf16 GEMM image of a (strided view of a) trainable weight: refreshed once per step by the engine's
+    parameter bank, built on the spot otherwise (bank.py)."""
+    return weight_bf16(w2d)
 
 
-def _w3(w):        # [O, I, 3, 3] -> [O, 9*I], k = tap*I + i (im2col3x3 order)
-    return w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+def _derived_bf16(kind, w, dst_shape, dst_view_shape, src_view):
+    return derived((kind, w.data_ptr()), dst_shape, BF, lambda t: [(t.view(dst_view_shape), src_view)], device=w.device)
 
 
-def _w3_grad(g, w):  # [O, 9*I] -> [O, I, 3, 3]
+def _wb_w3(w):       # [O, I, 3, 3] -> bf16 [O, 9*I], k = tap*I + i (im2col3x3 order)
+    w = w.detach()
+    O, I = w.shape[:2]
+    return _derived_bf16("w3", w, (O, 9 * I), (O, 3, 3, I), w.permute(0, 2, 3, 1))
+
+
+def _wb_w3T(w):      # -> bf16 [9*I, O] for the dgrad GEMM
+    w = w.detach()
+    O, I = w.shape[:2]
+    return _derived_bf16("w3T", w, (9 * I, O), (3, 3, I, O), w.permute(2, 3, 1, 0))
+
+
+def _w3_grad(g, w):  # [O, 9*I] -> view shaped [O, I, 3, 3]
     O, I = w.shape[0], w.shape[1]
-    return g.view(O, 3, 3, I).permute(0, 3, 1, 2).contiguous()
+    return g.view(O, 3, 3, I).permute(0, 3, 1, 2)
 
 
 def _bn(x, bn: nn.BatchNorm2d, training, act=ACT_NONE, out_dtype=F32, out2_dtype=None, chan_scale=None, rpi=0):
@@ -54,12 +67,12 @@ def _bn_bwd(dy, x, mean, rstd, bn, training, act=ACT_NONE, dx_dtype=F32, chan_sc
 
 def _conv3_fwd(x_bf, w, B, H, W):
     cols = ops.im2col3x3(x_bf, B, H, W)
-    return ops.gemm(cols, _wb(_w3(w)), out_dtype=F32), cols
+    return ops.gemm(cols, _wb_w3(w), out_dtype=F32), cols
 
 
 def _conv3_bwd(dy_bf, cols, w, B, H, W):
     """-> (dx fp32 [M, I], dW like w)."""
-    dcols = ops.gemm(dy_bf, _wb(_w3(w).t()))
+    dcols = ops.gemm(dy_bf, _wb_w3T(w))
     dx = ops.col2im3x3(dcols, B, H, W, w.shape[1])
     return dx, _w3_grad(ops.gemm_tn(dy_bf, cols), w)
 
@@ -69,25 +82,36 @@ def _w2(w):          # 1x1 conv weight [O, I, 1, 1] -> [O, I]
 
 
 def _grads(plist, gd):
-    return tuple(gd.get(id(p)) for p in plist)
+    return deliver(plist, [gd.get(id(p)) for p in plist])
 
 
 def _put(gd, p, g):
-    g = g.reshape(p.shape)
-    gd[id(p)] = g if id(p) not in gd else gd[id(p)] + g
+    """g: a view shaped like p, or something that reshapes to it without a copy"""
+    assert id(p) not in gd
+    gd[id(p)] = g if g.shape == p.shape else g.view(p.shape)
 
 
 # ---------------------------------------------------------------------------------------------- FPN + SEFusion
-def _ct_w(w):        # ConvTranspose2d weight [Ci, Co, 2, 2] -> GEMM weight [(dy,dx,co), ci]
-    return w.detach().permute(2, 3, 1, 0).reshape(4 * w.shape[1], w.shape[0])
+def _wb_ct(w):       # ConvTranspose2d weight [Ci, Co, 2, 2] -> bf16 GEMM weight [(dy,dx,co), ci]
+    w = w.detach()
+    Ci, Co = w.shape[:2]
+    return _derived_bf16("ct", w, (4 * Co, Ci), (2, 2, Co, Ci), w.permute(2, 3, 1, 0))
 
 
-def _ct_wT(w):       # -> [ci, (dy,dx,co)] for the dgrad GEMM
-    return w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], 4 * w.shape[1])
+def _wb_ctT(w):      # -> bf16 [ci, (dy,dx,co)] for the dgrad GEMM
+    w = w.detach()
+    Ci, Co = w.shape[:2]
+    return _derived_bf16("ctT", w, (Ci, 4 * Co), (Ci, 2, 2, Co), w.permute(0, 2, 3, 1))
 
 
-def _ct_grad(g, w):  # [(dy,dx,co), ci] -> [Ci, Co, 2, 2]
-    return g.view(2, 2, w.shape[1], w.shape[0]).permute(3, 2, 0, 1).contiguous()
+def _ct_grad(g, w):  # [(dy,dx,co), ci] -> view shaped [Ci, Co, 2, 2]
+    return g.view(2, 2, w.shape[1], w.shape[0]).permute(3, 2, 0, 1)
+
+
+def _rep4(b):        # ConvTranspose bias repeated over the four sub-pixels
+    b = b.detach()
+    C = b.shape[0]
+    return derived(("rep4", b.data_ptr()), (4 * C,), F32, lambda t: [(t.view(4, C), b.expand(4, C))], device=b.device)
 
 
 def fpn_fusion_params(model):
@@ -119,14 +143,14 @@ class FpnFusionFn(torch.autograd.Function):
         for mi, m in enumerate("xy"):
             f1, f2 = getattr(model, f"fpn1{m}"), getattr(model, f"fpn2{m}")
             dm = db[mi * M3:(mi + 1) * M3]
-            t1 = ops.gemm(dm, _wb(_ct_w(f1[0].weight)), bias=f1[0].bias.detach().repeat(4), out_dtype=F32).view(4 * M3, C)
+            t1 = ops.gemm(dm, _wb_ct(f1[0].weight), bias=_rep4(f1[0].bias), out_dtype=F32).view(4 * M3, C)
             if m == "x":
                 n1, mean, rstd = ops.layernorm_fwd(t1, f1[1].ln.weight, f1[1].ln.bias, f1[1].ln.eps, out_dtype=BF)
             else:
                 n1, _, mean, rstd = _bn(t1, f1[1], training, out_dtype=BF)
             a1 = ops.act(n1, ACT_GELU)
-            r1 = ops.gemm(a1, _wb(_ct_w(f1[3].weight)), bias=f1[3].bias.detach().repeat(4)).view(16 * M3, C)
-            r2 = ops.gemm(dm, _wb(_ct_w(f2[0].weight)), bias=f2[0].bias.detach().repeat(4)).view(4 * M3, C)
+            r1 = ops.gemm(a1, _wb_ct(f1[3].weight), bias=_rep4(f1[3].bias)).view(16 * M3, C)
+            r2 = ops.gemm(dm, _wb_ct(f2[0].weight), bias=_rep4(f2[0].bias)).view(4 * M3, C)
             r3 = d2[mi * M3:(mi + 1) * M3]
             r4, arg = ops.maxpool2_fwd(r3, B, h, w)
             r[m] = (r1, r2, r3, r4)
@@ -180,12 +204,12 @@ class FpnFusionFn(torch.autograd.Function):
             ops.maxpool2_bwd(dr[m][3], s["arg"], dd, B, h, w, accumulate=True)
             # fpn2
             dY = dr[m][1].view(M3, 4 * C)
-            ops.gemm(dY, _wb(_ct_wT(f2[0].weight)), residual=dd, out=dd)
+            ops.gemm(dY, _wb_ctT(f2[0].weight), residual=dd, out=dd)
             _put(gd, f2[0].weight, _ct_grad(ops.gemm_tn(dY, dm), f2[0].weight))
             _put(gd, f2[0].bias, ops.bias_grad(dY.view(4 * M3, C)))
             # fpn1: second ConvT -> GELU -> norm -> first ConvT
             dY2 = dr[m][0].view(4 * M3, 4 * C)
-            dn1 = ops.gemm(dY2, _wb(_ct_wT(f1[3].weight)), act=2, aux=s["n1"])
+            dn1 = ops.gemm(dY2, _wb_ctT(f1[3].weight), act=2, aux=s["n1"])
             _put(gd, f1[3].weight, _ct_grad(ops.gemm_tn(dY2, s["a1"]), f1[3].weight))
             _put(gd, f1[3].bias, ops.bias_grad(dY2.view(16 * M3, C)))
             if m == "x":
@@ -198,7 +222,7 @@ class FpnFusionFn(torch.autograd.Function):
                 dt1, dgam, dbet = _bn_bwd(dn1, s["t1"], s["mean"], s["rstd"], f1[1], training, dx_dtype=BF)
                 _put(gd, f1[1].weight, dgam); _put(gd, f1[1].bias, dbet)
             dY1 = dt1.view(M3, 4 * C)
-            ops.gemm(dY1, _wb(_ct_wT(f1[0].weight)), residual=dd, out=dd)
+            ops.gemm(dY1, _wb_ctT(f1[0].weight), residual=dd, out=dd)
             _put(gd, f1[0].weight, _ct_grad(ops.gemm_tn(dY1, dm), f1[0].weight))
             _put(gd, f1[0].bias, ops.bias_grad(dY1.view(4 * M3, C)))
         return (ddeep.view(2 * B, h, w, C), None, None) + _grads(plist, gd)
@@ -444,22 +468,24 @@ class SegHeadFn(torch.autograd.Function):
             raise NotImplementedError(f"num_classes > {NCLS_PAD}")
         c, cols = _conv3_fwd(x, head[0][0].weight, B, H, W)
         hb, _, mean, rstd = _bn(c, head[0][1], training, act=ACT_RELU6, out_dtype=BF, chan_scale=drop_mask, rpi=H * W)
-        wp = torch.zeros((NCLS_PAD, wcls.shape[1]), dtype=BF, device=x.device)
-        wp[:ncls] = _w2(wcls)
+        w2c = _w2(wcls)
+        wp = derived(("cls", w2c.data_ptr()), (NCLS_PAD, wcls.shape[1]), BF, lambda t: [(t[:ncls], w2c)], device=x.device)
         lg = ops.gemm(hb, wp, out_dtype=F32)
         logits = ops.up_final_fwd(lg, B, H, W, ncls, scale)
-        ctx.save_for_backward(cols, c, mean, rstd, hb, wp, drop_mask)
+        ctx.save_for_backward(cols, c, mean, rstd, hb, drop_mask)
         ctx.head, ctx.geom, ctx.scale, ctx.training, ctx.plist = head, geom, scale, training, plist
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
-        cols, c, mean, rstd, hb, wp, drop_mask = ctx.saved_tensors
+        cols, c, mean, rstd, hb, drop_mask = ctx.saved_tensors
         head, (B, H, W), training = ctx.head, ctx.geom, ctx.training
         ncls = head[2][0].weight.shape[0]
         gd = {}
         dlg = ops.up_final_bwd(dlogits.contiguous(), NCLS_PAD, B, H, W, ncls, ctx.scale)
-        dhb = ops.gemm(dlg, wp.t().contiguous())
+        w2c = _w2(head[2][0].weight)
+        wpT = derived(("clsT", w2c.data_ptr()), (w2c.shape[1], NCLS_PAD), BF, lambda t: [(t[:, :ncls], w2c.t())], device=dlg.device)
+        dhb = ops.gemm(dlg, wpT)
         _put(gd, head[2][0].weight, ops.gemm_tn(dlg, hb)[:ncls])
         dc, dg, dbt = _bn_bwd(dhb, c, mean, rstd, head[0][1], training, act=ACT_RELU6, dx_dtype=BF, chan_scale=drop_mask, rpi=H * W)
         _put(gd, head[0][1].weight, dg); _put(gd, head[0][1].bias, dbt)

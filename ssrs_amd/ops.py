@@ -671,3 +671,31 @@ def confusion(pred_u8, gt_i64, n_classes):
     cm = torch.zeros((n_classes, n_classes), dtype=torch.int64, device=pred_u8.device)
     call("mfnet_confusion", pred_u8.data_ptr(), gt_i64.data_ptr(), cm.data_ptr(), n_classes, pred_u8.numel(), _stream(pred_u8))
     return cm
+
+
+# ------------------------------------------------------------------------------------------ batched strided copies
+def gather(pairs, accumulate=False):
+    """One launch (per 48 pairs) for many small strided copies: pairs = [(dst_view, src_view)] with equal
+    logical shapes of at most 4 dims (expanded / permuted / sliced views welcome), src fp32, dst fp32 (assign,
+    or += with accumulate) or bf16 (assign); all dst of one call share a dtype."""
+    import ctypes
+    if not pairs:
+        return
+    ddt = pairs[0][0].dtype
+    desc = (ctypes.c_int64 * (14 * len(pairs)))()
+    k = 0
+    for dst, src in pairs:
+        _chk(dst, src)
+        assert src.dtype == torch.float32 and dst.dtype == ddt and tuple(dst.shape) == tuple(src.shape), (dst.shape, src.shape)
+        nd = dst.dim()
+        assert nd <= 4
+        pad = 4 - nd
+        desc[k] = src.data_ptr()
+        desc[k + 1] = dst.data_ptr()
+        for i in range(4):
+            j = i - pad
+            desc[k + 2 + i] = dst.shape[j] if j >= 0 else 1
+            desc[k + 6 + i] = src.stride(j) if j >= 0 else 0
+            desc[k + 10 + i] = dst.stride(j) if j >= 0 else 0
+        k += 14
+    call("mfnet_gather_segments", ctypes.cast(desc, ctypes.c_void_p), len(pairs), _DT[ddt], 1 if accumulate else 0, _stream(pairs[0][0]))

@@ -29,6 +29,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import ops
+from .bank import ParamBank
 
 _ALIGN = 64          # elements: every tensor starts on a 256-byte boundary inside the flat buffers
 
@@ -127,9 +128,16 @@ class TrainEngine:
         self._works = []
         self._bucket_size = [self.bucket_of.count(b) for b in range(len(self.bucket_bounds))]
         self._hooks = []
-        if self.world > 1 and not self.use_graph:
-            for i, p in enumerate(self.params):
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(self.bucket_of[i])))
+        # Gradients are added into flat_g by the modules' backward passes themselves (bank.deliver: one gather
+        # launch per module instead of one autograd `grad += g` per tensor); the bucket counters are notified
+        # from there. The autograd hook stays for any tensor whose gradient still arrives the ordinary way.
+        self.bank = ParamBank()
+        for i, p in enumerate(self.params):
+            notify = None
+            if self.world > 1 and not self.use_graph:
+                notify = self._make_hook(self.bucket_of[i])
+                self._hooks.append(p.register_post_accumulate_grad_hook(notify))
+            p._mfnet_sink = (p.grad, notify)
         self.steps = 0
 
     # ---- schedule (optim.lr_scheduler.MultiStepLR, trainer.py:118-122)
@@ -171,11 +179,12 @@ class TrainEngine:
 
     def forward_backward(self, rgb, dsm, target, want_pred=False):
         """-> (acc [4] device tensor: sum w*nll, sum w, #correct, #valid ; pred uint8 | None)."""
-        out = self.model(rgb, dsm, mode="Train")
-        out = out.contiguous()
-        acc, pred = ops.ce_loss_fwd(out, target, self.class_weight, self.ignore_index, want_pred=want_pred)
-        d = ops.ce_loss_bwd(out, target, acc, self.class_weight, self.ignore_index, 1.0)
-        out.backward(d)
+        with self.bank:          # refreshes every operand derived from trainable weights, then serves them
+            out = self.model(rgb, dsm, mode="Train")
+            out = out.contiguous()
+            acc, pred = ops.ce_loss_fwd(out, target, self.class_weight, self.ignore_index, want_pred=want_pred)
+            d = ops.ce_loss_bwd(out, target, acc, self.class_weight, self.ignore_index, 1.0)
+            out.backward(d)
         return acc, pred
 
     def optimizer_step(self):

@@ -25,6 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .bank import deliver, derived
 
 BF = torch.bfloat16
 
@@ -83,9 +84,50 @@ def _rel_tables(attn: nn.Module, kh: int, kw: int):
 # ---------------------------------------------------------------------------------------------
 # forward/backward building blocks (plain functions on tensors; no autograd inside)
 # ---------------------------------------------------------------------------------------------
+def _ptrs(*ts):
+    return tuple(t.data_ptr() for t in ts)
+
+
+def _stack2(kind, a, b, transpose=False):
+    """[2, ...] fp32 stack of two (optionally transposed) 2-D factors, kept per step by the parameter bank."""
+    a, b = a.detach(), b.detach()
+    if transpose:
+        a, b = a.t(), b.t()
+    return derived((kind, transpose) + _ptrs(a, b), (2,) + tuple(a.shape), torch.float32,
+                   lambda t: [(t[0], a), (t[1], b)], device=a.device)
+
+
 def _down(x_bf, A_x, A_y, half):
     """a[m] = x[m] @ A_g^T with the modality-specific A (rows [0,half) -> A_x, rest -> A_y)."""
-    return ops.skinny_nt(x_bf, torch.stack([A_x.detach(), A_y.detach()]), rows_per_group=half).contiguous()
+    return ops.skinny_nt(x_bf, _stack2("A", A_x, A_y), rows_per_group=half).contiguous()
+
+
+def _qkv_lora_V(Bx, By, D, r, transposed=False):
+    """Per-modality up-projection of the q,v LoRA as a dense [3D, 2r] factor (zero rows for k; q uses rank
+    slots [0,r), v slots [r,2r)), stacked over the two modalities; `transposed` gives [2, 2r, 3D]."""
+    Bx, By = Bx.detach(), By.detach()
+
+    def fill(t):
+        pairs = []
+        for g, Bm in enumerate((Bx, By)):
+            if transposed:
+                pairs += [(t[g, :r, :D], Bm[:D].t()), (t[g, r:, 2 * D:], Bm[D:].t())]
+            else:
+                pairs += [(t[g, :D, :r], Bm[:D]), (t[g, 2 * D:, r:], Bm[D:])]
+        return pairs
+    shape = (2, 2 * r, 3 * D) if transposed else (2, 3 * D, 2 * r)
+    return derived(("qkvV", transposed) + _ptrs(Bx, By), shape, torch.float32, fill, device=Bx.device)
+
+
+def _mix_V(lin, transposed=False):
+    """[N, 2r] = [Bx | By] of a lora.Linear (or its transpose [2r, N])."""
+    Bx, By = lin.lora_Bx.detach(), lin.lora_By.detach()
+    N, r = Bx.shape
+    if transposed:
+        return derived(("mixVt",) + _ptrs(Bx, By), (2 * r, N), torch.float32,
+                       lambda t: [(t[:r], Bx.t()), (t[r:], By.t())], device=Bx.device)
+    return derived(("mixV",) + _ptrs(Bx, By), (N, 2 * r), torch.float32,
+                   lambda t: [(t[:, :r], Bx), (t[:, r:], By)], device=Bx.device)
 
 
 def _tn_groups(y_bf, u, half, transposed, scale=1.0):
@@ -115,22 +157,21 @@ class _LoraAttnBranch(torch.autograd.Function):
         h2 = h.reshape(M, D)
         ln, mean, rstd = ops.layernorm_fwd(h2, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
         a = _down(ln, Ax, Ay, half)
-        V = torch.zeros((2, 3 * D, 2 * r), dtype=torch.float32, device=h.device)
-        for g, Bm in enumerate((Bx, By)):
-            V[g, :D, :r] = Bm[:D]
-            V[g, 2 * D:, r:] = Bm[D:]
+        V = _qkv_lora_V(Bx, By, D, r)
         qkv = ops.gemm(ln, w_bf16(attn.qkv.weight), bias=attn.qkv.bias, U=a, V=V, rows_per_group=half,
                        n_groups=2, lr_scale=1.0 / r)
         o, lse, tb = _attention(qkv, attn, 2 * B, Sh, Sw, heads, ws)
         out = ops.gemm(o, w_bf16(attn.proj.weight), bias=attn.proj.bias, residual=h2, out_dtype=torch.float32)
-        ctx.save_for_backward(h2, mean, rstd, ln, a, V, qkv, o, lse, Ax, Ay)
+        ctx.save_for_backward(h2, mean, rstd, ln, a, qkv, o, lse)
         ctx.blk, ctx.geom, ctx.tb = blk, geom, tb
+        ctx.params = (Ax, Ay, Bx, By)
         return out.view(h.shape)
 
     @staticmethod
     def backward(ctx, dout):
-        h2, mean, rstd, ln, a, V, qkv, o, lse, Ax, Ay = ctx.saved_tensors
+        h2, mean, rstd, ln, a, qkv, o, lse = ctx.saved_tensors
         blk, (B, Sh, Sw, heads, ws), (tbl, tblT, Lh, Lw) = ctx.blk, ctx.geom, ctx.tb
+        Ax, Ay, Bx, By = ctx.params
         attn = blk.attn
         M, D = h2.shape
         half = M // 2
@@ -141,15 +182,15 @@ class _LoraAttnBranch(torch.autograd.Function):
         dO = ops.gemm(d_bf, wT_bf16(attn.proj.weight))
         dqkv = ops.attn_bwd(qkv, attn.qkv.bias, tbl, tblT, o, dO, lse, 2 * B, Sh, Sw, heads, ws, Lh, Lw, hd ** -0.5)
         s = 1.0 / r
-        da = ops.skinny_nt(dqkv, V.transpose(1, 2).contiguous(), scale=s, rows_per_group=half).contiguous()
+        da = ops.skinny_nt(dqkv, _qkv_lora_V(Bx, By, D, r, transposed=True), scale=s, rows_per_group=half).contiguous()
         dVx, dVy = _tn_groups(dqkv, a, half, False, s)
-        dBx = torch.cat([dVx[:D, :r], dVx[2 * D:, r:]], 0)
-        dBy = torch.cat([dVy[:D, :r], dVy[2 * D:, r:]], 0)
         dAx, dAy = _tn_groups(ln, da, half, True)
-        At = torch.stack([Ax.t(), Ay.t()]).contiguous()            # [2, D, 2r]
-        dln = ops.gemm(dqkv, wT_bf16(attn.qkv.weight), U=da, V=At, rows_per_group=half, n_groups=2)
+        dln = ops.gemm(dqkv, wT_bf16(attn.qkv.weight), U=da, V=_stack2("A", Ax, Ay, transpose=True), rows_per_group=half, n_groups=2)
         dh, _ = ops.layernorm_bwd(dln, h2, mean, rstd, blk.norm1.weight, dres=d2)
-        return dh.view(dout.shape), None, None, dAx, dAy, dBx, dBy
+        rows_q, rows_v = slice(0, D), slice(D, 2 * D)
+        grads = deliver((Ax, Ay, Bx, By), (dAx, dAy, [(rows_q, dVx[:D, :r]), (rows_v, dVx[2 * D:, r:])],
+                                           [(rows_q, dVy[:D, :r]), (rows_v, dVy[2 * D:, r:])]))
+        return (dh.view(dout.shape), None, None) + grads
 
 
 def _mix_linear_fwd(x_bf, lin, half, act, residual):
@@ -157,30 +198,29 @@ def _mix_linear_fwd(x_bf, lin, half, act, residual):
     r = lin.lora_Ax.shape[0]
     a = _down(x_bf, lin.lora_Ax, lin.lora_Ay, half)
     U = ops.lora_mix_fwd(a, lin.lora_wx, lin.lora_wy)
-    V = torch.cat([lin.lora_Bx, lin.lora_By], 1).contiguous()      # [N, 2r]
+    V = _mix_V(lin)                                                # [N, 2r]
     if act:
         out, pre = ops.gemm(x_bf, w_bf16(lin.weight), bias=lin.bias, U=U, V=V, act=1, want_pre=True)
     else:
         out = ops.gemm(x_bf, w_bf16(lin.weight), bias=lin.bias, U=U, V=V, residual=residual,
                        out_dtype=torch.float32 if residual is not None else BF)
         pre = None
-    return out, pre, (a, U, V)
+    return out, pre, (a, U)
 
 
 def _mix_linear_bwd(d_bf, x_bf, lin, saved, half, gelu_aux=None):
-    """-> (dx bf16, dAx, dAy, dBx, dBy, dwx, dwy). d_bf: grad of the layer output (bf16, after any
-    activation backward of the NEXT layer); gelu_aux: this layer's INPUT pre-activation if the input
-    was GELU(pre) (then dx is the grad w.r.t. pre)."""
-    a, U, V = saved
+    """-> (dx bf16, (dAx, dAy, dBx, dBy, dwx, dwy) as strided views). d_bf: grad of the layer output (bf16,
+    after any activation backward of the NEXT layer); gelu_aux: this layer's INPUT pre-activation if the
+    input was GELU(pre) (then dx is the grad w.r.t. pre)."""
+    a, U = saved
     r = a.shape[1]
-    P = ops.skinny_nt(d_bf, V.t().contiguous())
+    P = ops.skinny_nt(d_bf, _mix_V(lin, transposed=True))
     da, dw = ops.lora_mix_bwd(P, a, lin.lora_wx, lin.lora_wy)
     dV = ops.skinny_tn(d_bf, U, False)
     dAx, dAy = _tn_groups(x_bf, da, half, True)
-    At = torch.stack([lin.lora_Ax.t(), lin.lora_Ay.t()]).contiguous()
-    dx = ops.gemm(d_bf, wT_bf16(lin.weight), U=da, V=At, rows_per_group=half, n_groups=2,
-                  act=2 if gelu_aux is not None else 0, aux=gelu_aux)
-    return dx, dAx, dAy, dV[:, :r].contiguous(), dV[:, r:].contiguous(), dw[0:1].clone(), dw[1:2].clone()
+    dx = ops.gemm(d_bf, wT_bf16(lin.weight), U=da, V=_stack2("A", lin.lora_Ax, lin.lora_Ay, transpose=True),
+                  rows_per_group=half, n_groups=2, act=2 if gelu_aux is not None else 0, aux=gelu_aux)
+    return dx, (dAx, dAy, dV[:, :r], dV[:, r:], dw[0:1], dw[1:2])
 
 
 class _LoraMlpBranch(torch.autograd.Function):
@@ -201,17 +241,16 @@ class _LoraMlpBranch(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        h2, mean, rstd, ln, act, pre, a1, U1, V1, a2, U2, V2 = ctx.saved_tensors
+        h2, mean, rstd, ln, act, pre, a1, U1, a2, U2 = ctx.saved_tensors
         blk = ctx.blk
         M, D = h2.shape
         half = M // 2
         d2 = dout.reshape(M, D).contiguous()
         d_bf = ops.cast(d2, BF)
-        dpre, dA2x, dA2y, dB2x, dB2y, dw2x, dw2y = _mix_linear_bwd(d_bf, act, blk.mlp.lin2, (a2, U2, V2), half, gelu_aux=pre)
-        dln, dA1x, dA1y, dB1x, dB1y, dw1x, dw1y = _mix_linear_bwd(dpre, ln, blk.mlp.lin1, (a1, U1, V1), half)
+        dpre, g2 = _mix_linear_bwd(d_bf, act, blk.mlp.lin2, (a2, U2), half, gelu_aux=pre)
+        dln, g1 = _mix_linear_bwd(dpre, ln, blk.mlp.lin1, (a1, U1), half)
         dh, _ = ops.layernorm_bwd(dln, h2, mean, rstd, blk.norm2.weight, dres=d2)
-        # order must match LoraBlock._mlp_params()
-        return (dh.view(dout.shape), None, dA1x, dA1y, dB1x, dB1y, dw1x, dw1y, dA2x, dA2y, dB2x, dB2y, dw2x, dw2y)
+        return (dh.view(dout.shape), None) + deliver(blk._mlp_params(), g1 + g2)     # order of LoraBlock._mlp_params()
 
 
 class _Neck(torch.autograd.Function):
@@ -319,12 +358,14 @@ class _StandaloneMixLinear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        xb, a, U, V = ctx.saved_tensors
+        xb, a, U = ctx.saved_tensors
         N = dout.shape[-1]
         M = dout.numel() // N
+        lin = ctx.lin
         d_bf = ops.cast(dout.reshape(M, N).contiguous(), BF)
-        dx, dAx, dAy, dBx, dBy, dwx, dwy = _mix_linear_bwd(d_bf, xb, ctx.lin, (a, U, V), M // 2)
-        return dx.float().view(*dout.shape[:-1], -1), None, dAx, dAy, dBx, dBy, dwx, dwy
+        dx, g = _mix_linear_bwd(d_bf, xb, lin, (a, U), M // 2)
+        params = (lin.lora_Ax, lin.lora_Ay, lin.lora_Bx, lin.lora_By, lin.lora_wx, lin.lora_wy)
+        return (dx.float().view(*dout.shape[:-1], -1), None) + deliver(params, g)
 
 
 class MergedLinear(nn.Linear, LoRALayer):

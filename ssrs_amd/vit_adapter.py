@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .bank import deliver, weight_bf16
 from .vit import BF, Adapter, _attention, _geom, w_bf16, wT_bf16
 
 
@@ -43,7 +44,7 @@ class MLPBlock(nn.Module):
 
 # ---- trainable dense layer on a row range: forward + (dgrad, wgrad, bias grad) -------------------
 def _dense_fwd(x_bf, W, b, act=False, residual=None, out=None, out_dtype=BF):
-    wb = ops.cast(W.detach().contiguous(), BF) if W.numel() % 8 == 0 else W.detach().to(BF)
+    wb = weight_bf16(W)
     if act:
         return ops.gemm(x_bf, wb, bias=b, act=1, want_pre=True)
     return ops.gemm(x_bf, wb, bias=b, residual=residual, out=out, out_dtype=out_dtype)
@@ -51,7 +52,7 @@ def _dense_fwd(x_bf, W, b, act=False, residual=None, out=None, out_dtype=BF):
 
 def _dense_bwd(d_bf, x_bf, W, gelu_aux=None):
     """-> (dx bf16, dW fp32, db fp32) for y = x W^T + b."""
-    wT = ops.cast(W.detach().t().contiguous(), BF)
+    wT = weight_bf16(W.t())
     dx = ops.gemm(d_bf, wT, act=2 if gelu_aux is not None else 0, aux=gelu_aux)
     dW = ops.gemm_tn(d_bf, x_bf)
     db = ops.bias_grad(d_bf)
@@ -84,6 +85,7 @@ class _AdapterAttnBranch(torch.autograd.Function):
             pres.append(p)
         ctx.save_for_backward(h2, mean, rstd, qkv, o, lse, op, acts[0], acts[1], pres[0], pres[1], w1x, w2x, w1y, w2y)
         ctx.blk, ctx.geom, ctx.tb = blk, geom, tb
+        ctx.params = (w1x, b1x, w2x, b2x, w1y, b1y, w2y, b2y)
         return hm.view(h.shape)
 
     @staticmethod
@@ -107,7 +109,7 @@ class _AdapterAttnBranch(torch.autograd.Function):
         dqkv = ops.attn_bwd(qkv, attn.qkv.bias, tbl, tblT, o, dO, lse, 2 * B, Sh, Sw, heads, ws, Lh, Lw, hd ** -0.5)
         dln = ops.gemm(dqkv, wT_bf16(attn.qkv.weight))
         dh, _ = ops.layernorm_bwd(dln, h2, mean, rstd, blk.norm1.weight, dres=d2)
-        return (dh.view(dout.shape), None, None, *grads)
+        return (dh.view(dout.shape), None, None) + deliver(ctx.params, grads)
 
 
 class _AdapterMlpBranch(torch.autograd.Function):
@@ -133,6 +135,7 @@ class _AdapterMlpBranch(torch.autograd.Function):
         out = ops.adapter_mix(hm, ada, wx, wy)
         ctx.save_for_backward(h2, mean, rstd, ln, pre, ada, acts[0], acts[1], pres[0], pres[1], w1x, w2x, w1y, w2y, wx, wy)
         ctx.blk = blk
+        ctx.params = (w1x, b1x, w2x, b2x, w1y, b1y, w2y, b2y, wx, wy)
         return out.view(h.shape)
 
     @staticmethod
@@ -155,7 +158,7 @@ class _AdapterMlpBranch(torch.autograd.Function):
             ops.add_bf16(dxl, dln[sl], dln[sl])
             grads += [dW1, db1, dW2, db2]
         dh, _ = ops.layernorm_bwd(dln, h2, mean, rstd, blk.norm2.weight, dres=d2)
-        return (dh.view(dout.shape), None, *grads, dw[0:1].clone(), dw[1:2].clone())
+        return (dh.view(dout.shape), None) + deliver(ctx.params, grads + [dw[0:1], dw[1:2]])
 
 
 def _ad_params(a: Adapter):
