@@ -214,8 +214,8 @@ class FpnFusionFn(torch.autograd.Function):
             _put(gd, f1[3].bias, ops.bias_grad(dY2.view(16 * M3, C)))
             if m == "x":
                 ln = f1[1].ln
-                dgam = torch.zeros(C, dtype=F32, device=db.device)
-                dbet = torch.zeros(C, dtype=F32, device=db.device)
+                dgam = ops.zeros(C, db.device)
+                dbet = ops.zeros(C, db.device)
                 _, dt1 = ops.layernorm_bwd(dn1, s["t1"], s["mean"], s["rstd"], ln.weight, want_f32=False, want_bf16=True, dgamma=dgam, dbeta=dbet)
                 _put(gd, ln.weight, dgam); _put(gd, ln.bias, dbet)
             else:

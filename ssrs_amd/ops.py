@@ -74,6 +74,51 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, want_f32=True, want_bf16=
 
 
 # ------------------------------------------------------------------------------------------ GEMM
+class ZeroArena:
+    """Zero-initialised fp32 scratch outputs of one train step, carved out of ONE buffer that is cleared by a
+    single fill at the start of the step (the step has ~250 small "adds into its output" results; a fill
+    launch each costs ~1 ms per step). The first step only records the demand; later steps bump-allocate.
+    Tensors taken from the arena are valid until the next step begins."""
+    current = None
+
+    def __init__(self):
+        self.buf, self.off, self.need = None, 0, 0
+
+    def __enter__(self):
+        ZeroArena.current = self
+        self.off = 0
+        if self.buf is not None:
+            self.buf.zero_()
+        return self
+
+    def __exit__(self, *exc):
+        ZeroArena.current = None
+        if self.buf is None and self.need:
+            self.buf = torch.empty(int(self.need * 1.25) + 4096, dtype=torch.float32, device=self.dev)
+        return False
+
+    def take(self, shape, device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        span = (n + 63) // 64 * 64
+        if self.buf is None or self.off + span > self.buf.numel() or self.buf.device != device:
+            self.need += span
+            self.dev = device
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        t = self.buf[self.off:self.off + n].view(shape)
+        self.off += span
+        return t
+
+
+def zeros(shape, device):
+    """fp32 zeros: from the active step arena if there is one, else a fresh tensor."""
+    if isinstance(shape, int):
+        shape = (shape,)
+    a = ZeroArena.current
+    return a.take(tuple(shape), device) if a is not None else torch.zeros(shape, dtype=torch.float32, device=device)
+
+
 def gemm(a, w, *, bias=None, U=None, V=None, rows_per_group=0, n_groups=1, lr_scale=1.0, act=0, aux=None,
          want_pre=False, residual=None, res_row_mod=0, out=None, out_dtype=torch.bfloat16, k_splits=1):
     """out = a @ w^T (+bias +U V_g^T) -> act -> (+residual). a [M,K] bf16, w [N,K] bf16.
@@ -136,7 +181,7 @@ def skinny_tn(y, u, transposed: bool, scale=1.0, out=None, n_groups=1):
     R = u.shape[1]
     assert u.dtype == torch.float32 and u.stride(1) == 1 and u.shape[0] == M and M % n_groups == 0
     if out is None:
-        out = torch.zeros((n_groups, R, C) if transposed else (n_groups, C, R), dtype=torch.float32, device=y.device)
+        out = zeros((n_groups, R, C) if transposed else (n_groups, C, R), y.device)
     assert out.is_contiguous()
     Mg = M // n_groups
     nws = _lib.lib().mfnet_skinny_tn_workspace_floats(Mg, C, R, n_groups)
@@ -193,7 +238,7 @@ def lora_mix_bwd(P, a, wx, wy):
     _chk(P, a, wx, wy)
     M, r = a.shape
     da = torch.empty_like(a)
-    dw = torch.zeros(2, dtype=torch.float32, device=a.device)
+    dw = zeros(2, a.device)
     call("mfnet_lora_mix_bwd", P.data_ptr(), a.data_ptr(), wx.data_ptr(), wy.data_ptr(), da.data_ptr(),
          dw.data_ptr(), M, r, _stream(a))
     return da, dw
@@ -299,7 +344,7 @@ def adapter_mix(h, ada, wx, wy, out=None):
 def adapter_mix_bwd(dh, ada, wx, wy):
     M, D = dh.shape
     dada = torch.empty((M, D), dtype=torch.bfloat16, device=dh.device)
-    dw = torch.zeros(2, dtype=torch.float32, device=dh.device)
+    dw = zeros(2, dh.device)
     call("mfnet_adapter_mix_bwd", dh.data_ptr(), ada.data_ptr(), wx.data_ptr(), wy.data_ptr(), dada.data_ptr(),
          dw.data_ptr(), None, M, D, _stream(dh))
     return dada, dw
@@ -309,7 +354,7 @@ def bias_grad(dy, out=None):
     _chk(dy)
     dy2, M, N, ld = _rows2d(dy)
     if out is None:
-        out = torch.zeros(N, dtype=torch.float32, device=dy.device)
+        out = zeros(N, dy.device)
     call("mfnet_bias_grad", dy2.data_ptr(), ld, out.data_ptr(), M, N, _stream(dy))
     return out
 
@@ -360,7 +405,7 @@ def colsum(x, G, P, want_sq=False):
     _chk(x)
     C = x.shape[-1]
     assert x.is_contiguous() and x.numel() == G * P * C
-    s = torch.zeros((2 if want_sq else 1, G, C), dtype=torch.float32, device=x.device)
+    s = zeros((2 if want_sq else 1, G, C), x.device)
     call("mfnet_colsum", x.data_ptr(), _dt(x), s[0].data_ptr(), s[1].data_ptr() if want_sq else None, G, P, C, _stream(x))
     return s[0], (s[1] if want_sq else None)
 
@@ -369,7 +414,7 @@ def coldot(a, b, G, P):
     _chk(a, b)
     C = a.shape[-1]
     assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel() == G * P * C
-    out = torch.zeros((G, C), dtype=torch.float32, device=a.device)
+    out = zeros((G, C), a.device)
     call("mfnet_coldot", a.data_ptr(), _dt(a), b.data_ptr(), _dt(b), out.data_ptr(), G, P, C, _stream(a))
     return out
 
@@ -400,7 +445,7 @@ def bn_backward(dy, x, mean, rstd, gamma, beta, training, act=ACT_NONE, chan_sca
     _chk(dy, x)
     rows, C = x.shape
     assert dy.is_contiguous() and x.is_contiguous() and dy.shape == x.shape
-    sums = torch.zeros((2, C), dtype=torch.float32, device=x.device)
+    sums = zeros((2, C), x.device)
     call("mfnet_bn_bwd_reduce", dy.data_ptr(), _dt(dy), x.data_ptr(), _dt(x), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
          beta.data_ptr(), act, _p(chan_scale), rows_per_image, sums[0].data_ptr(), sums[1].data_ptr(), rows, C, _stream(x))
     dx = torch.empty((rows, C), dtype=dx_dtype, device=x.device)
@@ -442,8 +487,8 @@ def dwconv_bwd(dy, x, w, B, H, W, k, ext, want_bias=False):
     assert dy.is_contiguous() and x.is_contiguous() and x.dtype == torch.float32
     dx = torch.empty_like(x)
     call("mfnet_dwconv_bwd_data", dy.data_ptr(), _dt(dy), w.data_ptr(), dx.data_ptr(), B, H, W, C, k, 1 if ext else 0, _stream(x))
-    dw = torch.zeros(w.shape, dtype=torch.float32, device=x.device)
-    db = torch.zeros(C, dtype=torch.float32, device=x.device) if want_bias else None
+    dw = zeros(w.shape, x.device)
+    db = zeros(C, x.device) if want_bias else None
     call("mfnet_dwconv_bwd_weight", dy.data_ptr(), _dt(dy), x.data_ptr(), dw.data_ptr(), _p(db), B, H, W, C, k, 1 if ext else 0, _stream(x))
     return dx, dw, db
 
@@ -460,7 +505,7 @@ def gla_attn_bwd(qkv, table, dout, B, H, W, heads, scale):
     _chk(qkv, table, dout)
     assert dout.is_contiguous() and dout.dtype == torch.float32
     dqkv = torch.empty_like(qkv)
-    dtable = torch.zeros_like(table)
+    dtable = zeros(table.shape, table.device)
     call("mfnet_gla_attn_bwd", qkv.data_ptr(), table.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), dtable.data_ptr(), B, H, W, heads,
          qkv.shape[1] // (3 * heads), 8, float(scale), _stream(qkv))
     return dqkv, dtable
@@ -498,7 +543,7 @@ def upfuse_bwd(df, x, skip, perm, w, eps, B, H, W, dskip_dtype=torch.bfloat16):
     assert df.is_contiguous() and df.dtype == torch.float32
     dx = torch.empty_like(x)
     dskip = torch.empty(skip.shape, dtype=dskip_dtype, device=x.device)
-    dw = torch.zeros(2, dtype=torch.float32, device=x.device)
+    dw = zeros(2, x.device)
     sums = torch.empty(2, dtype=torch.float32, device=x.device)
     call("mfnet_upfuse_bwd", df.data_ptr(), x.data_ptr(), skip.data_ptr(), _dt(skip), perm, w.data_ptr(), float(eps), dx.data_ptr(),
          dskip.data_ptr(), _dt(dskip), dw.data_ptr(), sums.data_ptr(), B, H, W, C, _stream(x))
@@ -555,10 +600,10 @@ def se_gate_bwd(dg, pooled_sum, P, W1, W2, relu6, z, g, has_bias):
     Cr = W1.shape[0]
     dev = W1.device
     dpool = torch.empty((B, C), dtype=torch.float32, device=dev)
-    dW1 = torch.zeros(W1.shape, dtype=torch.float32, device=dev)
-    dW2 = torch.zeros(W2.shape, dtype=torch.float32, device=dev)
-    db1 = torch.zeros(Cr, dtype=torch.float32, device=dev) if has_bias else None
-    db2 = torch.zeros(C, dtype=torch.float32, device=dev) if has_bias else None
+    dW1 = zeros(W1.shape, dev)
+    dW2 = zeros(W2.shape, dev)
+    db1 = zeros(Cr, dev) if has_bias else None
+    db2 = zeros(C, dev) if has_bias else None
     call("mfnet_se_gate_bwd", dg.data_ptr(), pooled_sum.data_ptr(), P, W1.data_ptr(), W2.data_ptr(), 1 if relu6 else 0, z.data_ptr(),
          g.data_ptr(), dpool.data_ptr(), dW1.data_ptr(), _p(db1), dW2.data_ptr(), _p(db2), B, C, Cr, _stream(W1))
     return dpool, dW1, db1, dW2, db2

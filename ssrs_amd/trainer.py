@@ -132,6 +132,7 @@ class TrainEngine:
         # launch per module instead of one autograd `grad += g` per tensor); the bucket counters are notified
         # from there. The autograd hook stays for any tensor whose gradient still arrives the ordinary way.
         self.bank = ParamBank()
+        self.arena = ops.ZeroArena()
         for i, p in enumerate(self.params):
             notify = None
             if self.world > 1 and not self.use_graph:
@@ -179,7 +180,7 @@ class TrainEngine:
 
     def forward_backward(self, rgb, dsm, target, want_pred=False):
         """-> (acc [4] device tensor: sum w*nll, sum w, #correct, #valid ; pred uint8 | None)."""
-        with self.bank:          # refreshes every operand derived from trainable weights, then serves them
+        with self.bank, self.arena:   # bank: refreshes every operand derived from trainable weights, then serves them
             out = self.model(rgb, dsm, mode="Train")
             out = out.contiguous()
             acc, pred = ops.ce_loss_fwd(out, target, self.class_weight, self.ignore_index, want_pred=want_pred)
