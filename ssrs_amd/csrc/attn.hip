@@ -2,13 +2,20 @@
 // qkv bias) and global, with decomposed relative-position bias, flash-style online softmax.
 // See attn_common.h for the reference semantics (lora_block.py:169-196, 248-317).
 //
-// Workgroup = 4 waves x 16 queries of one (image-modality, head, window); keys are staged in LDS in
-// chunks of 256: K row-major [key][64] (XOR-swizzled 16-B chunks, ds_read_b128 fragments) and V
-// transposed [hd][key] so that P.V contracts over a register-contiguous key index.
+// Workgroup = 4 waves x 16 queries of one (image-modality, head, window); blockIdx.x enumerates only the
+// (window, 64-query tile) pairs that exist. Keys are staged in LDS in chunks of 128: K and V row-major
+// [key][64] (XOR-swizzled 16-B chunks; K fragments by ds_read_b128, V^T fragments by the gfx950 transposing
+// read ds_read_b64_tr_b16 - no transposed image is ever stored).
 // Scores are computed "swapped" (S^T = K.Q^T: key on the accumulator rows, query on the lane), so
 //   * softmax statistics are per-lane scalars (4 lane groups combined with two shuffles),
 //   * the bf16 P^T accumulator registers ARE the B operand of O^T = V^T.P^T (keys permuted identically
 //     in the V^T fragment read), no LDS round trip.
+// The rel-pos bias T[q][KH-1-kh+qh] + T[q][Lh+KW-1-kw+qw] is NOT gathered per score (that made the kernel
+// VALU-bound: ~10 of ~20 instructions per score). With the query's table rows shifted into "slots"
+// T'[q][j] (j < KH: T[q][j+qh]; then T[q][Lh+(j-KH)+qw]) it is the product G.T'^T of the 0/1 indicator
+// G[key][j] = (j == KH-1-kh) | (j == KH+KW-1-kw) with T' - one more MFMA k-step per 32 slots, fed by an
+// indicator image staged beside K. T' is split hi + lo in bf16 (two k-steps), so the bias keeps fp32-level
+// accuracy, and it is pre-divided by `scale` so one multiply serves the whole logit.
 #include "attn_common.h"
 
 struct AttnFwdParams {
@@ -20,32 +27,33 @@ struct AttnFwdParams {
   float* lse;             // [G, heads, T]
 };
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdParams p) {
+template <int NSG>      // 32-slot groups of the indicator product: ceil((KH + KW) / 32) rounded up to 1, 2 or 4
+__global__ __launch_bounds__(256, NSG == 1 ? 4 : 2) void attn_fwd_kernel(const AttnFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const AttnGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int T = g.Sh * g.Sw;
-  const int nwin = g.nWh * g.nWw;
-  const int gi = blockIdx.z / nwin, win = blockIdx.z - gi * nwin;
-  const int wi = win / g.nWw, wj = win - wi * g.nWw;
-  const int head = blockIdx.y;
+  const int gi = blockIdx.z, head = blockIdx.y;
+  int wi, wj, qt0;
+  att_locate_tile(g, blockIdx.x, &wi, &wj, &qt0);
   const int nq = num_queries(g, wi, wj);
-  const int qt0 = blockIdx.x * ATT_QT;
-  if (qt0 >= nq) return;
   const int Nk = g.KH * g.KW;
   const int TLD = g.NT + 4;
+  const int nsg = (g.KH + g.KW + 31) >> 5;
+  const int regionA = att_region_a(g.NT);
 
-  unsigned char* K_lds = smem;                                     // [256][64] bf16, swizzled
-  bf16_t* Vt_lds = (bf16_t*)(smem + ATT_KC * ATT_HD * 2);          // [64][ATT_VT_LD]
-  int* kidx_lds = (int*)(smem + ATT_KC * ATT_HD * 2 + ATT_HD * ATT_VT_LD * 2);   // [256] packed (idx_h | idx_w<<16)
-  float* T_lds = (float*)(kidx_lds + ATT_KC);                      // [64][NT+4]
+  unsigned char* K_lds = smem;                                     // [128][64] bf16, swizzled
+  unsigned char* V_lds = smem + ATT_KC * ATT_HD * 2;               // [128][64] bf16, swizzled
+  float* T_lds = (float*)smem;                                     // [64][NT+4]: only until the key loop starts
+  unsigned char* G_lds = smem + regionA;                           // [nsg][128][32] bf16 indicator rows
 
   const int64_t row_base = (int64_t)gi * T;
   const int64_t ld = 3 * (int64_t)g.D;
 
   // ---- this lane's query (column of every accumulator tile)
   const QueryPos qp = query_pos(g, wi, wj, qt0 + wave * 16 + fr);
+  const bool wave_active = qt0 + wave * 16 < nq;                   // wave-uniform: waves without a query only stage
   bf16x8_t qf[2];
   {
     const bf16_t* qptr = p.qkv + (row_base + qp.tok) * ld + head * ATT_HD + 8 * fq;
@@ -53,27 +61,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdParams p) {
     qf[1] = *reinterpret_cast<const bf16x8_t*>(qptr + 32);
     if (!qp.valid) { qf[0] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}; qf[1] = qf[0]; }
   }
-  // ---- T^T = tbl . Q^T  -> T_lds[query][table row]
-  float* Trow = T_lds + (wave * 16 + fr) * TLD;
-  att_table_product(p.tbl, g.NT, qf, Trow, fr, fq);
-  const int qoff_h = qp.qh, qoff_w = qp.qw;
-
-  float m_run = -INFINITY, l_run = 0.f;
-  f32x4_t o[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) o[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
   // this thread always stages 16-B chunk `ch` of a key row: the padded-key value of that chunk (the qkv bias,
   // rounded to bf16 like every other qkv entry) is kept in registers
   const int ch = tid & 7;
   const PaddedKV pad = att_padded_kv(p.qkv_bias, g.D, head, ch);
 
-  for (int kc = 0; kc < Nk; kc += ATT_KC) {
-    // ---- stage K (row-major, swizzled), V^T and the per-key bias indices. All global loads of the chunk
-    // are issued first, unconditionally (padded / out-of-range keys read row 0 and are replaced afterwards):
-    // one memory round trip per chunk, overlapping the other waves' tail of the previous chunk.
-    u32x4_t kv[ATT_KC / 32], vv[ATT_KC / 32];
-    int kmeta[ATT_KC / 32];
+  // All global loads of a key chunk are issued first, unconditionally: padded / out-of-range keys read row 0
+  // and are replaced when the registers are written to LDS. (Prefetching a chunk ahead costs 40 VGPRs, i.e.
+  // one resident workgroup per CU, and measured 20 % slower.)
+  u32x4_t kv[ATT_KC / 32], vv[ATT_KC / 32];
+  int kkind[ATT_KC / 32];
+  auto issue_chunk = [&](int kc) {
 #pragma unroll
     for (int it = 0; it < ATT_KC / 32; ++it) {
       const int kg = kc + it * 32 + (tid >> 3);
@@ -82,84 +80,104 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdParams p) {
       const bf16_t* src = p.qkv + (row_base + max(tok, 0)) * ld + g.D + head * ATT_HD + ch * 8;
       kv[it] = *reinterpret_cast<const u32x4_t*>(src);
       vv[it] = *reinterpret_cast<const u32x4_t*>(src + g.D);
-      kmeta[it] = (tok < 0 ? (tok == -2 ? 2 : 1) : 0) | (((g.KH - 1 - kh) | ((g.Lh + g.KW - 1 - kw) << 16)) << 2);
+      kkind[it] = tok < 0 ? (tok == -2 ? 2 : 1) : 0;               // 0 real, 1 padded, 2 beyond the window
     }
-    __syncthreads();   // previous chunk fully consumed (also orders T_lds writes on the first pass)
+  };
+  // ---- T^T = tbl . Q^T  -> T_lds[query][table row], then this lane's slots of T' / scale as bf16 hi + lo
+  float* Trow = T_lds + (wave * 16 + fr) * TLD;
+  att_table_product(p.tbl, g.NT, qf, Trow, fr, fq);
+  bf16x8_t tqh[NSG], tql[NSG];
+  att_slot_fragments<NSG>(g, Trow, qp.qh, qp.qw, fq, nsg, tqh, tql);
+
+  float m_run = -INFINITY, l_run = 0.f;
+  const float cs = g.scale * 1.4426950408889634f;                  // logits are scale * acc; exp via exp2
+  f32x4_t o[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) o[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  for (int kc = 0; kc < Nk; kc += ATT_KC) {
+    issue_chunk(kc);
+    __syncthreads();   // previous chunk fully consumed (first pass: every wave has read its T rows)
 #pragma unroll
     for (int it = 0; it < ATT_KC / 32; ++it) {
       const int kl = it * 32 + (tid >> 3);
-      const int kind = kmeta[it] & 3;          // 0 real, 1 padded, 2 beyond the window
-      u32x4_t k4 = kind == 0 ? kv[it] : pad.k, v4 = kind == 0 ? vv[it] : pad.v;
-      if (kind == 2) { k4 = (u32x4_t){0u, 0u, 0u, 0u}; v4 = k4; }
+      u32x4_t k4 = kkind[it] == 0 ? kv[it] : pad.k, v4 = kkind[it] == 0 ? vv[it] : pad.v;
+      if (kkind[it] == 2) { k4 = (u32x4_t){0u, 0u, 0u, 0u}; v4 = k4; }
       *reinterpret_cast<u32x4_t*>(K_lds + kl * 128 + ((ch ^ kswz(kl)) << 4)) = k4;
-      bf16_t* vt = Vt_lds + (ch * 8) * ATT_VT_LD + kl;
-      vt[0 * ATT_VT_LD] = (bf16_t)(v4.x & 0xffff); vt[1 * ATT_VT_LD] = (bf16_t)(v4.x >> 16);
-      vt[2 * ATT_VT_LD] = (bf16_t)(v4.y & 0xffff); vt[3 * ATT_VT_LD] = (bf16_t)(v4.y >> 16);
-      vt[4 * ATT_VT_LD] = (bf16_t)(v4.z & 0xffff); vt[5 * ATT_VT_LD] = (bf16_t)(v4.z >> 16);
-      vt[6 * ATT_VT_LD] = (bf16_t)(v4.w & 0xffff); vt[7 * ATT_VT_LD] = (bf16_t)(v4.w >> 16);
-      if (ch == 0) kidx_lds[kl] = kmeta[it] >> 2;
+      *reinterpret_cast<u32x4_t*>(V_lds + kl * 128 + ((ch ^ kswz(kl)) << 4)) = v4;
     }
+    att_stage_indicator(g, G_lds, kc, Nk, nsg, tid);
     __syncthreads();
     const int kvalid = min(ATT_KC, Nk - kc);
-    for (int kt = 0; kt * 64 < kvalid; ++kt) {
-      // ---- S^T tiles (16 keys x 16 queries each)
-      f32x4_t s[4];
+    if (wave_active) {
+      for (int kt = 0; kt * 64 < kvalid; ++kt) {
+        // ---- S^T tiles (16 keys x 16 queries each): K.Q^T + G.T'^T
+        f32x4_t s[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        const int kr = kt * 64 + 16 * t + fr;
+        for (int t = 0; t < 4; ++t) {
+          s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          const int kr = kt * 64 + 16 * t + fr;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(K_lds + kr * 128 + (((fq + 4 * ks) ^ kswz(kr)) << 4));
-          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+          for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(K_lds + kr * 128 + (((fq + 4 * ks) ^ kswz(kr)) << 4));
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+          }
+#pragma unroll
+          for (int c = 0; c < NSG; ++c) {
+            if (c < nsg) {
+              const bf16x8_t gf = *reinterpret_cast<const bf16x8_t*>(G_lds + c * (ATT_KC * ATT_GROW) + kr * ATT_GROW + ((fq ^ gswz(kr)) << 4));
+              s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, tqh[c], s[t], 0, 0, 0);
+              s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, tql[c], s[t], 0, 0, 0);
+            }
+          }
         }
-      }
-      // ---- scale + rel-pos bias + mask, tile max
-      float tmax = -INFINITY;
+        if (kt * 64 + 64 > kvalid) {       // only the window's last tile holds keys beyond Nk
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+          for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int kl = kt * 64 + 16 * t + 4 * fq + r;
-          const int pk = kidx_lds[kl];
-          const float bias = Trow[(pk & 0xffff) + qoff_h] + Trow[(pk >> 16) + qoff_w];
-          float v = s[t][r] * g.scale + bias;
-          v = (kl < kvalid) ? v : -INFINITY;
-          s[t][r] = v;
-          tmax = fmaxf(tmax, v);
+            for (int r = 0; r < 4; ++r)
+              if (kt * 64 + 16 * t + 4 * fq + r >= kvalid) s[t][r] = -INFINITY;
         }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float m_new = fmaxf(m_run, tmax);
-      const float alpha = __expf(m_run - m_new);    // m_run = -inf on the first tile -> 0
-      m_run = m_new;
-      float psum = 0.f;
+        float tmax = -INFINITY;
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t) tmax = fmaxf(tmax, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);    // m_run = -inf on the first tile -> 0
+        const float mc = m_new * cs;
+        m_run = m_new;
+        float psum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __expf(s[t][r] - m_new);
-          s[t][r] = e;
-          psum += e;
-        }
-      l_run = l_run * alpha + psum;
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { o[u][0] *= alpha; o[u][1] *= alpha; o[u][2] *= alpha; o[u][3] *= alpha; }
-      // ---- O^T += V^T . P^T ; element j of k-step s2 <-> key 32*s2 + 16*(j>>2) + 4*fq + (j&3)
+          for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(s[t][r], cs, -mc));
+            s[t][r] = e;
+            psum += e;
+          }
+        l_run = l_run * alpha + psum;
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        union { bf16x8_t v; unsigned int w[4]; } pf;
-        pf.w[0] = pack_bf16x2(s[2 * s2][0], s[2 * s2][1]);
-        pf.w[1] = pack_bf16x2(s[2 * s2][2], s[2 * s2][3]);
-        pf.w[2] = pack_bf16x2(s[2 * s2 + 1][0], s[2 * s2 + 1][1]);
-        pf.w[3] = pack_bf16x2(s[2 * s2 + 1][2], s[2 * s2 + 1][3]);
+        for (int u = 0; u < 4; ++u) { o[u][0] *= alpha; o[u][1] *= alpha; o[u][2] *= alpha; o[u][3] *= alpha; }
+        // ---- O^T += V^T . P^T ; element j of k-step s2 <-> key 32*s2 + 16*(j>>2) + 4*fq + (j&3). The V^T
+        // fragment comes from two transposing reads of 4 keys x 16 head-dims each (lane 4q+p of a 16-lane
+        // group addresses key q, head-dims 4p..4p+3 of the block; lane i receives head-dim i of the 4 keys).
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const bf16_t* vp = Vt_lds + (16 * u + fr) * ATT_VT_LD + kt * 64 + 32 * s2 + 4 * fq;
-          union { bf16x8_t v; u32x2_t h[2]; } vf;
-          vf.h[0] = *reinterpret_cast<const u32x2_t*>(vp);
-          vf.h[1] = *reinterpret_cast<const u32x2_t*>(vp + 16);
-          o[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[u], 0, 0, 0);
+        for (int s2 = 0; s2 < 2; ++s2) {
+          union { bf16x8_t v; unsigned int w[4]; } pf;
+          pf.w[0] = pack_bf16x2(s[2 * s2][0], s[2 * s2][1]);
+          pf.w[1] = pack_bf16x2(s[2 * s2][2], s[2 * s2][3]);
+          pf.w[2] = pack_bf16x2(s[2 * s2 + 1][0], s[2 * s2 + 1][1]);
+          pf.w[3] = pack_bf16x2(s[2 * s2 + 1][2], s[2 * s2 + 1][3]);
+          const int vrow = kt * 64 + 32 * s2 + 4 * fq + (fr >> 2);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const unsigned char* va = V_lds + vrow * 128 + (((2 * u + ((fr >> 1) & 1)) ^ kswz(vrow)) << 4) + ((fr & 1) << 3);
+            union { bf16x8_t v; s16x4_t h[2]; } vf;
+            vf.h[0] = att_tr_read(va);
+            vf.h[1] = att_tr_read(va + 16 * 128);
+            o[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[u], 0, 0, 0);
+          }
         }
       }
     }
@@ -177,7 +195,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdParams p) {
       w.y = pack_bf16x2(o[u][2] * inv, o[u][3] * inv);
       *reinterpret_cast<u32x2_t*>(op + 16 * u) = w;
     }
-    if (fq == 0 && p.lse) p.lse[((int64_t)gi * g.heads + head) * T + qp.tok] = m_run + __logf(l_run);
+    if (fq == 0 && p.lse) p.lse[((int64_t)gi * g.heads + head) * T + qp.tok] = m_run * g.scale + __logf(l_run);
   }
 }
 
@@ -199,7 +217,19 @@ int attn_fill_geom(AttnGeom* g, int64_t G, int64_t Sh, int64_t Sw, int64_t heads
 }
 
 static size_t attn_fwd_lds(const AttnGeom& g) {
-  return (size_t)ATT_KC * ATT_HD * 2 + (size_t)ATT_HD * ATT_VT_LD * 2 + ATT_KC * 4 + (size_t)ATT_QT * (g.NT + 4) * 4;
+  return (size_t)att_region_a(g.NT) + (size_t)((g.KH + g.KW + 31) / 32) * ATT_KC * ATT_GROW;
+}
+
+// number of (window, 64-query tile) pairs of one image = grid.x of the query-tiled kernels
+int attn_query_tiles(const AttnGeom& g) {
+  int n = 0;
+  for (int wi = 0; wi < g.nWh; ++wi)
+    for (int wj = 0; wj < g.nWw; ++wj) {
+      const int rh = g.ws > 0 ? (g.ws < g.Sh - wi * g.ws ? g.ws : g.Sh - wi * g.ws) : g.Sh;
+      const int rw = g.ws > 0 ? (g.ws < g.Sw - wj * g.ws ? g.ws : g.Sw - wj * g.ws) : g.Sw;
+      n += (rh * rw + ATT_QT - 1) / ATT_QT;
+    }
+  return n;
 }
 
 extern "C" int mfnet_attn_fwd(const void* qkv, const float* qkv_bias, const void* tbl, void* out, float* lse,
@@ -213,14 +243,20 @@ extern "C" int mfnet_attn_fwd(const void* qkv, const float* qkv_bias, const void
   const size_t lds = attn_fwd_lds(p.g);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { mfnet_set_error("attn_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MFNET_ERR_HIP; }
     attr_set = true;
   }
-  const int maxq = p.g.ws > 0 ? p.g.ws * p.g.ws : p.g.Sh * p.g.Sw;
-  dim3 grid((unsigned)ceil_div64(maxq, ATT_QT), (unsigned)heads, (unsigned)(G * p.g.nWh * p.g.nWw));
+  MF_CHECK_ARG(p.g.KH + p.g.KW <= 128, "attn_fwd: key grid %dx%d too large (KH + KW <= 128)", p.g.KH, p.g.KW);
+  dim3 grid((unsigned)attn_query_tiles(p.g), (unsigned)heads, (unsigned)G);
   MF_CHECK_ARG(grid.z <= 65535 && grid.y <= 65535, "attn_fwd: grid too large");
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), lds, stream, p);
+  MF_CHECK_ARG(lds <= 160 * 1024, "attn_fwd: LDS demand too large");
+  const int nsg = (p.g.KH + p.g.KW + 31) / 32;
+  if (nsg <= 1) hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, dim3(256), lds, stream, p);
+  else if (nsg == 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(256), lds, stream, p);
+  else hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(256), lds, stream, p);
   MF_LAUNCH_CHECK("attn_fwd");
   return MFNET_OK;
 }

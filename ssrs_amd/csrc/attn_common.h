@@ -56,6 +56,34 @@ __device__ __forceinline__ int key_token(const AttnGeom& g, int wi, int wj, int 
 }
 
 __device__ __forceinline__ int kswz(int row) { return row & 7; }   // 16-B chunk XOR for [row][64 hd] images
+__device__ __forceinline__ int gswz(int row) { return (row >> 2) & 3; }   // same for the 64-B indicator rows
+
+#define ATT_GROW 64        // bytes per key row of one 32-slot indicator image
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr_t;
+
+// LDS bytes shared by the K / V images (key loop) and the T table (before it)
+__host__ __device__ inline int att_region_a(int NT) {
+  const int kv = 2 * ATT_KC * ATT_HD * 2, t = ATT_QT * (NT + 4) * 4;
+  return kv > t ? kv : t;
+}
+
+// gfx950 transposing LDS read (ds_read_b64_tr_b16): see the forward kernel's P.V step for the lane roles
+__device__ __forceinline__ s16x4_t att_tr_read(const unsigned char* lds_addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(lds_addr));
+}
+
+// blockIdx.x -> (window, first query) over the (window, 64-query tile) pairs that exist
+__device__ __forceinline__ void att_locate_tile(const AttnGeom& g, int t, int* wi, int* wj, int* qt0) {
+  int i = 0, j = 0;
+  for (int w = 0; w < g.nWh * g.nWw; ++w) {
+    i = w / g.nWw; j = w - i * g.nWw;
+    const int nt = (num_queries(g, i, j) + ATT_QT - 1) / ATT_QT;
+    if (t < nt) break;
+    t -= nt;
+  }
+  *wi = i; *wj = j; *qt0 = t * ATT_QT;
+}
 
 // ---- shared device helpers of the forward / backward kernels ------------------------------------------
 
@@ -65,17 +93,17 @@ __device__ __forceinline__ int kswz(int row) { return row & 7; }   // 16-B chunk
 #define ATT_MAX_NT16 16
 __device__ __forceinline__ void att_table_product(const bf16_t* tbl, int NT, const bf16x8_t (&qf)[2], float* Trow, int fr, int fq) {
   const int nt16 = NT >> 4;
-  for (int t0 = 0; t0 < nt16; t0 += 6) {
-    bf16x8_t a0[6], a1[6];
+  for (int t0 = 0; t0 < nt16; t0 += 4) {
+    bf16x8_t a0[4], a1[4];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < 4; ++i) {
       const int t = min(t0 + i, nt16 - 1);
       const bf16_t* tp = tbl + (int64_t)(16 * t + fr) * ATT_HD + 8 * fq;
       a0[i] = *reinterpret_cast<const bf16x8_t*>(tp);
       a1[i] = *reinterpret_cast<const bf16x8_t*>(tp + 32);
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < 4; ++i) {
       if (t0 + i < nt16) {
         f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], qf[0], acc, 0, 0, 0);
@@ -96,4 +124,50 @@ __device__ __forceinline__ PaddedKV att_padded_kv(const float* qkv_bias, int D, 
   r.k.x = pack_bf16x2(a.x, a.y); r.k.y = pack_bf16x2(a.z, a.w); r.k.z = pack_bf16x2(b.x, b.y); r.k.w = pack_bf16x2(b.z, b.w);
   r.v.x = pack_bf16x2(c.x, c.y); r.v.y = pack_bf16x2(c.z, c.w); r.v.z = pack_bf16x2(d.x, d.y); r.v.w = pack_bf16x2(d.z, d.w);
   return r;
+}
+
+// This lane's 8 slots of each 32-slot group of T'[q][.] / scale, split into bf16 hi + lo fragments (B operand
+// of the indicator product). Slot j < KH reads T[q][j + qh]; slot KH + j' (j' < KW) reads T[q][Lh + j' + qw].
+template <int NSG>
+__device__ __forceinline__ void att_slot_fragments(const AttnGeom& g, const float* Trow, int qh, int qw, int fq, int nsg,
+                                                   bf16x8_t (&hi)[NSG], bf16x8_t (&lo)[NSG]) {
+  const float inv = 1.0f / g.scale;
+#pragma unroll
+  for (int c = 0; c < NSG; ++c) {
+    union { bf16x8_t v; unsigned int w[4]; } h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float x[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int sl = 32 * c + 8 * fq + 2 * i + e;
+        const int idx = sl < g.KH ? sl + qh : g.Lh + (sl - g.KH) + qw;
+        x[e] = (c < nsg && sl < g.KH + g.KW) ? Trow[idx] * inv : 0.f;
+      }
+      h.w[i] = pack_bf16x2(x[0], x[1]);
+      l.w[i] = pack_bf16x2(x[0] - bf16_lo(h.w[i]), x[1] - bf16_hi(h.w[i]));
+    }
+    hi[c] = h.v; lo[c] = l.v;
+  }
+}
+
+// Indicator rows of the chunk's keys: G[key][slot] = 1 for slot == KH-1-kh and slot == KH+KW-1-kw (bf16), zero
+// rows beyond Nk. Thread t fills half of key (t >> 1)'s row; images are [group][key][32 slots], 16-B chunks
+// XOR-swizzled by gswz(key).
+__device__ __forceinline__ void att_stage_indicator(const AttnGeom& g, unsigned char* G_lds, int kc, int Nk, int nsg, int tid) {
+  const int key = tid >> 1, kg = kc + key;
+  int jh = -1, jw = -1;
+  if (kg < Nk) { const int kh = kg / g.KW, kw = kg - kh * g.KW; jh = g.KH - 1 - kh; jw = g.KH + g.KW - 1 - kw; }
+  for (int cidx = (tid & 1) * 2 * nsg; cidx < ((tid & 1) + 1) * 2 * nsg; ++cidx) {
+    const int c = cidx >> 2, c4 = cidx & 3, s0 = 32 * c + 8 * c4;
+    u32x4_t w;
+    unsigned int ww[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int a = s0 + 2 * i, b = a + 1;
+      ww[i] = ((a == jh || a == jw) ? 0x3f80u : 0u) | ((b == jh || b == jw) ? 0x3f800000u : 0u);
+    }
+    w.x = ww[0]; w.y = ww[1]; w.z = ww[2]; w.w = ww[3];
+    *reinterpret_cast<u32x4_t*>(G_lds + c * (ATT_KC * ATT_GROW) + key * ATT_GROW + ((c4 ^ gswz(key)) << 4)) = w;
+  }
 }
