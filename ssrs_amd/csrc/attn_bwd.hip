@@ -28,37 +28,36 @@ struct AttnBwdParams {
 };
 
 // =============================================================================================== dQ
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p) {
+// Same structure as attn_fwd_kernel (attn.hip): compact (window, tile) grid, K / V row-major in LDS, rel-pos
+// bias as the indicator product G.T'^T. The two transposed operands of this kernel, K^T (dQ^T += K^T.dS^T) and
+// G^T (dT'^T += G^T.dS^T), are read from the SAME row-major images with ds_read_b64_tr_b16.
+template <int NSG>
+__global__ __launch_bounds__(256, NSG == 1 ? 3 : 2) void attn_bwd_dq_kernel(const AttnBwdParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const AttnGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int T = g.Sh * g.Sw;
-  const int nwin = g.nWh * g.nWw;
-  const int gi = blockIdx.z / nwin, win = blockIdx.z - gi * nwin;
-  const int wi = win / g.nWw, wj = win - wi * g.nWw;
-  const int head = blockIdx.y;
+  const int gi = blockIdx.z, head = blockIdx.y;
+  int wi, wj, qt0;
+  att_locate_tile(g, blockIdx.x, &wi, &wj, &qt0);
   const int nq = num_queries(g, wi, wj);
-  const int qt0 = blockIdx.x * ATT_QT;
-  if (qt0 >= nq) return;
   const int Nk = g.KH * g.KW;
   const int TLD = g.NT + 4;
+  const int nsg = (g.KH + g.KW + 31) >> 5;
 
-  unsigned char* K_lds = smem;                                        // [KC][64] swizzled
-  unsigned char* V_lds = smem + ATT_KC * ATT_HD * 2;                  // [KC][64] swizzled
-  bf16_t* Kt_lds = (bf16_t*)(smem + 2 * ATT_KC * ATT_HD * 2);         // [64][ATT_VT_LD]
-  int* kidx_lds = (int*)((unsigned char*)Kt_lds + ATT_HD * ATT_VT_LD * 2);
-  float* T_lds = (float*)(kidx_lds + ATT_KC);                         // [64][NT+4]
-  bf16_t* Gt_lds = (bf16_t*)(T_lds + ATT_QT * TLD);                   // [16*nG][ATT_VT_LD] key -> table-row indicators
-  float* dT_lds = (float*)smem;                                       // [64][NT+4], aliases K/V after the key loop
-  const int nG = (g.KH + g.KW + 15) >> 4;
+  unsigned char* K_lds = smem;                                        // [128][64] swizzled
+  unsigned char* V_lds = smem + ATT_KC * ATT_HD * 2;                  // [128][64] swizzled
+  float* T_lds = (float*)smem;                                        // [64][NT+4] before the key loop; dT after it
+  unsigned char* G_lds = smem + att_region_a(g.NT);                   // [nsg][128][32] bf16 indicator rows
 
   const int64_t row_base = (int64_t)gi * T;
   const int64_t ld = 3 * (int64_t)g.D;
   const QueryPos qp = query_pos(g, wi, wj, qt0 + wave * 16 + fr);
+  const bool wave_active = qt0 + wave * 16 < nq;
 
   bf16x8_t qf[2], dof[2];
-  float delta = 0.f, lse = 0.f;
+  float delta = 0.f, lse2 = 0.f;
   {
     const bf16x8_t z = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
     const bf16_t* qptr = p.qkv + (row_base + qp.tok) * ld + head * ATT_HD + 8 * fq;
@@ -70,6 +69,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
     dof[1] = *reinterpret_cast<const bf16x8_t*>(dptr + 32);
     const bf16x8_t o0 = *reinterpret_cast<const bf16x8_t*>(optr);
     const bf16x8_t o1 = *reinterpret_cast<const bf16x8_t*>(optr + 32);
+    lse2 = p.lse[((int64_t)gi * g.heads + head) * T + qp.tok] * 1.4426950408889634f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       delta += bf16_to_f32((bf16_t)dof[0][e]) * bf16_to_f32((bf16_t)o0[e]);
@@ -77,17 +77,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
     }
     delta += __shfl_xor(delta, 16, 64);
     delta += __shfl_xor(delta, 32, 64);
-    lse = p.lse[((int64_t)gi * g.heads + head) * T + qp.tok];
-    if (!qp.valid) { qf[0] = qf[1] = dof[0] = dof[1] = z; delta = 0.f; lse = 0.f; }
+    if (!qp.valid) { qf[0] = qf[1] = dof[0] = dof[1] = z; delta = 0.f; lse2 = 0.f; }
   }
-  // T^T = tbl . Q^T -> T_lds
+  // T^T = tbl . Q^T -> T_lds, then this lane's slots of T' / scale (attn.hip)
   float* Trow = T_lds + (wave * 16 + fr) * TLD;
-  float* dTrow = dT_lds + (wave * 16 + fr) * TLD;
   att_table_product(p.tbl, g.NT, qf, Trow, fr, fq);
+  bf16x8_t tqh[NSG], tql[NSG];
+  att_slot_fragments<NSG>(g, Trow, qp.qh, qp.qw, fq, nsg, tqh, tql);
+  const float cs = g.scale * 1.4426950408889634f;
 
-  f32x4_t dq[4], dgt[4];
+  f32x4_t dq[4], dgt[NSG][2];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) { dq[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dgt[u] = dq[u]; }
+  for (int u = 0; u < 4; ++u) dq[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < NSG; ++c) dgt[c][0] = dgt[c][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const int ch = tid & 7;          // this thread always stages 16-B chunk `ch` of a key row
   const PaddedKV pad = att_padded_kv(p.qkv_bias, g.D, head, ch);
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
   for (int kc = 0; kc < Nk; kc += ATT_KC) {
     // all global loads of the chunk first, unconditionally (see attn_fwd_kernel)
     u32x4_t kv[ATT_KC / 32], vv[ATT_KC / 32];
-    int kmeta[ATT_KC / 32];
+    int kkind[ATT_KC / 32];
 #pragma unroll
     for (int it = 0; it < ATT_KC / 32; ++it) {
       const int kg = kc + it * 32 + (tid >> 3);
@@ -104,101 +107,104 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
       const bf16_t* src = p.qkv + (row_base + max(tok, 0)) * ld + g.D + head * ATT_HD + ch * 8;
       kv[it] = *reinterpret_cast<const u32x4_t*>(src);
       vv[it] = *reinterpret_cast<const u32x4_t*>(src + g.D);
-      kmeta[it] = (tok < 0 ? (tok == -2 ? 2 : 1) : 0) | (kh << 2) | (kw << 10);
+      kkind[it] = tok < 0 ? (tok == -2 ? 2 : 1) : 0;
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < ATT_KC / 32; ++it) {
       const int kl = it * 32 + (tid >> 3);
-      const int kind = kmeta[it] & 3, kh = (kmeta[it] >> 2) & 0xff, kw = (kmeta[it] >> 10) & 0xff;
-      u32x4_t k4 = kind == 0 ? kv[it] : pad.k, v4 = kind == 0 ? vv[it] : pad.v;
-      if (kind == 2) { k4 = (u32x4_t){0u, 0u, 0u, 0u}; v4 = k4; }
+      u32x4_t k4 = kkind[it] == 0 ? kv[it] : pad.k, v4 = kkind[it] == 0 ? vv[it] : pad.v;
+      if (kkind[it] == 2) { k4 = (u32x4_t){0u, 0u, 0u, 0u}; v4 = k4; }
       *reinterpret_cast<u32x4_t*>(K_lds + kl * 128 + ((ch ^ kswz(kl)) << 4)) = k4;
       *reinterpret_cast<u32x4_t*>(V_lds + kl * 128 + ((ch ^ kswz(kl)) << 4)) = v4;
-      bf16_t* kt_ = Kt_lds + (ch * 8) * ATT_VT_LD + kl;
-      kt_[0 * ATT_VT_LD] = (bf16_t)(k4.x & 0xffff); kt_[1 * ATT_VT_LD] = (bf16_t)(k4.x >> 16);
-      kt_[2 * ATT_VT_LD] = (bf16_t)(k4.y & 0xffff); kt_[3 * ATT_VT_LD] = (bf16_t)(k4.y >> 16);
-      kt_[4 * ATT_VT_LD] = (bf16_t)(k4.z & 0xffff); kt_[5 * ATT_VT_LD] = (bf16_t)(k4.z >> 16);
-      kt_[6 * ATT_VT_LD] = (bf16_t)(k4.w & 0xffff); kt_[7 * ATT_VT_LD] = (bf16_t)(k4.w >> 16);
-      if (ch == 0) kidx_lds[kl] = (g.KH - 1 - kh) | ((g.Lh + g.KW - 1 - kw) << 16);
-      // indicator rows: thread (kl, ch) fills rows ch, ch+8, ... of column kl
-      const int jh = g.KH - 1 - kh, jw = g.KH + g.KW - 1 - kw;
-      const bool kin = kind != 2;
-      for (int j = ch; j < 16 * nG; j += 8) Gt_lds[j * ATT_VT_LD + kl] = (kin && (j == jh || j == jw)) ? (bf16_t)0x3f80 : (bf16_t)0;
     }
+    att_stage_indicator(g, G_lds, kc, Nk, nsg, tid);
     __syncthreads();
     const int kvalid = min(ATT_KC, Nk - kc);
-    for (int kt = 0; kt * 64 < kvalid; ++kt) {
-      f32x4_t s[4], dp[4];
+    if (wave_active) {
+      for (int kt = 0; kt * 64 < kvalid; ++kt) {
+        f32x4_t s[4], dp[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        dp[t] = s[t];
-        const int kr = kt * 64 + 16 * t + fr;
+        for (int t = 0; t < 4; ++t) {
+          s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          dp[t] = s[t];
+          const int kr = kt * 64 + 16 * t + fr;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int off = kr * 128 + (((fq + 4 * ks) ^ kswz(kr)) << 4);
-          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(K_lds + off), qf[ks], s[t], 0, 0, 0);
-          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(V_lds + off), dof[ks], dp[t], 0, 0, 0);
+          for (int ks = 0; ks < 2; ++ks) {
+            const int off = kr * 128 + (((fq + 4 * ks) ^ kswz(kr)) << 4);
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(K_lds + off), qf[ks], s[t], 0, 0, 0);
+            dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(V_lds + off), dof[ks], dp[t], 0, 0, 0);
+          }
+#pragma unroll
+          for (int c = 0; c < NSG; ++c) {
+            if (c < nsg) {
+              const bf16x8_t gf = *reinterpret_cast<const bf16x8_t*>(G_lds + c * (ATT_KC * ATT_GROW) + kr * ATT_GROW + ((fq ^ gswz(kr)) << 4));
+              s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, tqh[c], s[t], 0, 0, 0);
+              s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, tql[c], s[t], 0, 0, 0);
+            }
+          }
         }
-      }
+        const bool tail = kt * 64 + 64 > kvalid;       // only the window's last tile holds keys beyond Nk
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int kl = kt * 64 + 16 * t + 4 * fq + r;
-          const int pk = kidx_lds[kl];
-          const int ih = (pk & 0xffff) + qp.qh, iw = (pk >> 16) + qp.qw;
-          const float v = s[t][r] * g.scale + Trow[ih] + Trow[iw];
-          const float pr = (kl < kvalid && qp.valid) ? __expf(v - lse) : 0.f;
-          s[t][r] = pr * (dp[t][r] - delta);          // dS (unscaled)
-        }
-      // dQ^T += scale * K^T . dS^T and dG^T += G^T . dS^T   (key-permuted k-steps, as in the forward's P.V)
+          for (int r = 0; r < 4; ++r) {
+            float pr = __builtin_amdgcn_exp2f(fmaf(s[t][r], cs, -lse2));
+            if (tail && kt * 64 + 16 * t + 4 * fq + r >= kvalid) pr = 0.f;
+            s[t][r] = pr * (dp[t][r] - delta);          // dS (unscaled)
+          }
+        // dQ^T += K^T . dS^T and dT'^T += G^T . dS^T   (key-permuted k-steps, as in the forward's P.V; the
+        // transposed fragments come from the row-major images by ds_read_b64_tr_b16)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        union { bf16x8_t v; unsigned int w[4]; } pf;
-        pf.w[0] = pack_bf16x2(s[2 * s2][0], s[2 * s2][1]);
-        pf.w[1] = pack_bf16x2(s[2 * s2][2], s[2 * s2][3]);
-        pf.w[2] = pack_bf16x2(s[2 * s2 + 1][0], s[2 * s2 + 1][1]);
-        pf.w[3] = pack_bf16x2(s[2 * s2 + 1][2], s[2 * s2 + 1][3]);
+        for (int s2 = 0; s2 < 2; ++s2) {
+          union { bf16x8_t v; unsigned int w[4]; } pf;
+          pf.w[0] = pack_bf16x2(s[2 * s2][0], s[2 * s2][1]);
+          pf.w[1] = pack_bf16x2(s[2 * s2][2], s[2 * s2][3]);
+          pf.w[2] = pack_bf16x2(s[2 * s2 + 1][0], s[2 * s2 + 1][1]);
+          pf.w[3] = pack_bf16x2(s[2 * s2 + 1][2], s[2 * s2 + 1][3]);
+          const int krow = kt * 64 + 32 * s2 + 4 * fq + (fr >> 2);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const bf16_t* kp = Kt_lds + (16 * u + fr) * ATT_VT_LD + kt * 64 + 32 * s2 + 4 * fq;
-          union { bf16x8_t v; u32x2_t h[2]; } kf;
-          kf.h[0] = *reinterpret_cast<const u32x2_t*>(kp);
-          kf.h[1] = *reinterpret_cast<const u32x2_t*>(kp + 16);
-          dq[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf.v, pf.v, dq[u], 0, 0, 0);
-        }
+          for (int u = 0; u < 4; ++u) {
+            const unsigned char* ka = K_lds + krow * 128 + (((2 * u + ((fr >> 1) & 1)) ^ kswz(krow)) << 4) + ((fr & 1) << 3);
+            union { bf16x8_t v; s16x4_t h[2]; } kf;
+            kf.h[0] = att_tr_read(ka);
+            kf.h[1] = att_tr_read(ka + 16 * 128);
+            dq[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf.v, pf.v, dq[u], 0, 0, 0);
+          }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (u < nG) {
-            const bf16_t* gp = Gt_lds + (16 * u + fr) * ATT_VT_LD + kt * 64 + 32 * s2 + 4 * fq;
-            union { bf16x8_t v; u32x2_t h[2]; } gf;
-            gf.h[0] = *reinterpret_cast<const u32x2_t*>(gp);
-            gf.h[1] = *reinterpret_cast<const u32x2_t*>(gp + 16);
-            dgt[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf.v, pf.v, dgt[u], 0, 0, 0);
+          for (int c = 0; c < NSG; ++c) {
+            if (c < nsg) {
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                const unsigned char* ga = G_lds + c * (ATT_KC * ATT_GROW) + krow * ATT_GROW + (((2 * u + ((fr >> 1) & 1)) ^ gswz(krow)) << 4) + ((fr & 1) << 3);
+                union { bf16x8_t v; s16x4_t h[2]; } gf;
+                gf.h[0] = att_tr_read(ga);
+                gf.h[1] = att_tr_read(ga + 16 * ATT_GROW);
+                dgt[c][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf.v, pf.v, dgt[c][u], 0, 0, 0);
+              }
+            }
           }
         }
       }
     }
   }
   __syncthreads();   // K / V images dead: their LDS becomes dT
+  float* dTrow = T_lds + (wave * 16 + fr) * TLD;
 #pragma unroll
   for (int u = 0; u < 4; ++u) { dq[u][0] *= g.scale; dq[u][1] *= g.scale; dq[u][2] *= g.scale; dq[u][3] *= g.scale; }
   for (int t = 0; t < g.NT / 16; ++t) *reinterpret_cast<float4*>(dTrow + 16 * t + 4 * fq) = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
-  // dT[q][j + qh] = dG[q][j] (j < KH) ; dT[q][Lh + j' + qw] = dG[q][KH + j'] : one lane per (q, j), plain stores
+  // dT[q][j + qh] = dT'[q][j] (j < KH) ; dT[q][Lh + j' + qw] = dT'[q][KH + j'] : one lane per (q, slot), plain stores
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    if (u < nG) {
+  for (int c = 0; c < NSG; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int j = 16 * u + 4 * fq + r;
-        if (j < g.KH) dTrow[j + qp.qh] = dgt[u][r];
-        else if (j < g.KH + g.KW) dTrow[g.Lh + (j - g.KH) + qp.qw] = dgt[u][r];
+        const int j = 32 * c + 16 * u + 4 * fq + r;
+        if (j < g.KH) dTrow[j + qp.qh] = dgt[c][u][r];
+        else if (j < g.KH + g.KW) dTrow[g.Lh + (j - g.KH) + qp.qw] = dgt[c][u][r];
       }
-    }
-  }
   __syncthreads();
   // dQ^T += tbl^T . dT^T
   for (int s3 = 0; s3 < g.NT / 32; ++s3) {
@@ -226,37 +232,38 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
 }
 
 // ============================================================================================ dK, dV
-#define QT_LD (ATT_QT + 8)   // row length (elements) of the transposed [hd][query] images
-
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p) {
+// One workgroup per 64 REAL keys of a window (key on the lane), looping over the window's queries in chunks
+// of 64: dV^T += dO^T.P, dK^T += scale * Q^T.dS with the P / dS accumulator tiles reused as B operands. Q and
+// dO are staged row-major only; their transposes come from ds_read_b64_tr_b16. The rel-pos bias is the
+// product T'.G^T: T' (per query, hi + lo bf16 rows staged in LDS) times this lane's key indicator (registers).
+template <int NSG>
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const AttnBwdParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const AttnGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int T = g.Sh * g.Sw;
-  const int nwin = g.nWh * g.nWw;
-  const int gi = blockIdx.z / nwin, win = blockIdx.z - gi * nwin;
-  const int wi = win / g.nWw, wj = win - wi * g.nWw;
-  const int head = blockIdx.y;
+  const int gi = blockIdx.z, head = blockIdx.y;
+  int wi, wj, k0;
+  att_locate_tile(g, blockIdx.x, &wi, &wj, &k0);
   const int nq = num_queries(g, wi, wj);      // real keys of a window == its real queries
-  const int k0 = blockIdx.x * 64;
-  if (k0 >= nq) return;
   const int TLD = g.NT + 4;
+  const int nsg = (g.KH + g.KW + 31) >> 5;
 
   unsigned char* Q_lds = smem;                                   // [64][64] swizzled
   unsigned char* dO_lds = smem + ATT_QT * ATT_HD * 2;
-  bf16_t* Qt_lds = (bf16_t*)(smem + 2 * ATT_QT * ATT_HD * 2);    // [64][QT_LD]
-  bf16_t* dOt_lds = Qt_lds + ATT_HD * QT_LD;
-  float* lse_lds = (float*)(dOt_lds + ATT_HD * QT_LD);           // [64]
+  float* lse_lds = (float*)(smem + 2 * ATT_QT * ATT_HD * 2);     // [64] lse * log2(e); +huge for an absent query
   float* delta_lds = lse_lds + ATT_QT;                           // [64]
-  int* qpos_lds = (int*)(delta_lds + ATT_QT);                    // [64] packed (qh | qw<<8 | valid<<16)
-  float* T_lds = (float*)(qpos_lds + ATT_QT);                    // [64][NT+4]
+  unsigned char* TqH_lds = (unsigned char*)(delta_lds + ATT_QT); // [nsg][64][32 slots] bf16, hi part of T'/scale
+  unsigned char* TqL_lds = TqH_lds + nsg * ATT_QT * ATT_GROW;    // lo part
+  float* T_lds = (float*)(TqL_lds + nsg * ATT_QT * ATT_GROW);    // [64][NT+4]
 
   const int64_t row_base = (int64_t)gi * T;
   const int64_t ld = 3 * (int64_t)g.D;
 
-  // this lane's key (column of S / dP tiles)
+  // this lane's key (column of S / dP tiles) and its indicator slots
   const QueryPos kp = query_pos(g, wi, wj, k0 + wave * 16 + fr);
+  const bool wave_active = k0 + wave * 16 < nq;
   bf16x8_t kb[2], vb[2];
   {
     const bf16_t* kptr = p.qkv + (row_base + kp.tok) * ld + g.D + head * ATT_HD + 8 * fq;
@@ -265,19 +272,33 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
     vb[0] = *reinterpret_cast<const bf16x8_t*>(kptr + g.D);
     vb[1] = *reinterpret_cast<const bf16x8_t*>(kptr + g.D + 32);
   }
-  const int kbias_h = g.KH - 1 - kp.qh, kbias_w = g.Lh + g.KW - 1 - kp.qw;
+  bf16x8_t gk[NSG];
+  {
+    const int jh = g.KH - 1 - kp.qh, jw = g.KH + g.KW - 1 - kp.qw;
+#pragma unroll
+    for (int c = 0; c < NSG; ++c) {
+      union { bf16x8_t v; unsigned int w[4]; } u;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int a = 32 * c + 8 * fq + 2 * i, b = a + 1;
+        u.w[i] = ((a == jh || a == jw) ? 0x3f80u : 0u) | ((b == jh || b == jw) ? 0x3f800000u : 0u);
+      }
+      gk[c] = u.v;
+    }
+  }
+  const float cs = g.scale * 1.4426950408889634f;
 
   f32x4_t dk[4], dv[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) { dk[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[u] = dk[u]; }
 
   for (int qc = 0; qc < nq; qc += ATT_QT) {
-    // ---- stage Q / dO (row-major + transposed), lse, delta, query coordinates. All global loads first and
-    // unconditional (an invalid query reads the window's first token and is zeroed): one round trip.
+    // ---- stage Q / dO (row-major), lse, delta and the T' rows of the chunk's queries. All global loads first
+    // and unconditional (an absent query reads the window's first token and is zeroed): one round trip.
     const int ch = tid & 7;
     u32x4_t qv[2], dv_[2], ov[2];
     float lsev[2];
-    int qmeta[2];
+    bool qok[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const QueryPos qq = query_pos(g, wi, wj, qc + it * 32 + (tid >> 3));
@@ -285,88 +306,95 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
       dv_[it] = *reinterpret_cast<const u32x4_t*>(p.dout + (row_base + qq.tok) * g.D + head * ATT_HD + ch * 8);
       ov[it] = *reinterpret_cast<const u32x4_t*>(p.out + (row_base + qq.tok) * g.D + head * ATT_HD + ch * 8);
       lsev[it] = p.lse[((int64_t)gi * g.heads + head) * T + qq.tok];
-      qmeta[it] = qq.qh | (qq.qw << 8) | (qq.valid << 16);
+      qok[it] = qq.valid;
+    }
+    const QueryPos qw_ = query_pos(g, wi, wj, qc + wave * 16 + fr);      // this wave's 16 queries: table product
+    bf16x8_t qfx[2];
+    {
+      const bf16_t* qptr = p.qkv + (row_base + qw_.tok) * ld + head * ATT_HD + 8 * fq;
+      qfx[0] = *reinterpret_cast<const bf16x8_t*>(qptr);
+      qfx[1] = *reinterpret_cast<const bf16x8_t*>(qptr + 32);
+      if (!qw_.valid) { qfx[0] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}; qfx[1] = qfx[0]; }
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int ql = it * 32 + (tid >> 3);
-      const bool valid = (qmeta[it] >> 16) & 1;
-      if (!valid) { qv[it] = (u32x4_t){0u, 0u, 0u, 0u}; dv_[it] = qv[it]; ov[it] = qv[it]; }
+      if (!qok[it]) { qv[it] = (u32x4_t){0u, 0u, 0u, 0u}; dv_[it] = qv[it]; ov[it] = qv[it]; }
       *reinterpret_cast<u32x4_t*>(Q_lds + ql * 128 + ((ch ^ kswz(ql)) << 4)) = qv[it];
       *reinterpret_cast<u32x4_t*>(dO_lds + ql * 128 + ((ch ^ kswz(ql)) << 4)) = dv_[it];
-      bf16_t* a = Qt_lds + (ch * 8) * QT_LD + ql;
-      bf16_t* b = dOt_lds + (ch * 8) * QT_LD + ql;
-      const unsigned int qw_[4] = {qv[it].x, qv[it].y, qv[it].z, qv[it].w}, dw_[4] = {dv_[it].x, dv_[it].y, dv_[it].z, dv_[it].w},
-                         ow_[4] = {ov[it].x, ov[it].y, ov[it].z, ov[it].w};
+      const unsigned int dw_[4] = {dv_[it].x, dv_[it].y, dv_[it].z, dv_[it].w}, ow_[4] = {ov[it].x, ov[it].y, ov[it].z, ov[it].w};
       float dl = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        a[(2 * e) * QT_LD] = (bf16_t)(qw_[e] & 0xffff); a[(2 * e + 1) * QT_LD] = (bf16_t)(qw_[e] >> 16);
-        b[(2 * e) * QT_LD] = (bf16_t)(dw_[e] & 0xffff); b[(2 * e + 1) * QT_LD] = (bf16_t)(dw_[e] >> 16);
-        dl += bf16_lo(dw_[e]) * bf16_lo(ow_[e]) + bf16_hi(dw_[e]) * bf16_hi(ow_[e]);
-      }
+      for (int e = 0; e < 4; ++e) dl += bf16_lo(dw_[e]) * bf16_lo(ow_[e]) + bf16_hi(dw_[e]) * bf16_hi(ow_[e]);
       dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64); dl += __shfl_xor(dl, 4, 64);
       if (ch == 0) {
         delta_lds[ql] = dl;
-        lse_lds[ql] = valid ? lsev[it] : 0.f;
-        qpos_lds[ql] = qmeta[it];
+        lse_lds[ql] = qok[it] ? lsev[it] * 1.4426950408889634f : 1e30f;     // absent query: P = exp2(-huge) = 0
       }
     }
-    // ---- T^T = tbl . Q^T for this wave's 16 queries of the chunk -> T_lds[query][row]
     {
-      const QueryPos qq = query_pos(g, wi, wj, qc + wave * 16 + fr);
-      const bf16_t* qptr = p.qkv + (row_base + qq.tok) * ld + head * ATT_HD + 8 * fq;
-      bf16x8_t qf0 = *reinterpret_cast<const bf16x8_t*>(qptr), qf1 = *reinterpret_cast<const bf16x8_t*>(qptr + 32);
-      if (!qq.valid) { qf0 = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}; qf1 = qf0; }
       float* Trow = T_lds + (wave * 16 + fr) * TLD;
-      const bf16x8_t qfx[2] = {qf0, qf1};
       att_table_product(p.tbl, g.NT, qfx, Trow, fr, fq);
+      bf16x8_t th[NSG], tl[NSG];
+      att_slot_fragments<NSG>(g, Trow, qw_.qh, qw_.qw, fq, nsg, th, tl);
+      const int ql = wave * 16 + fr;
+#pragma unroll
+      for (int c = 0; c < NSG; ++c) {
+        if (c < nsg) {
+          const int off = c * (ATT_QT * ATT_GROW) + ql * ATT_GROW + ((fq ^ gswz(ql)) << 4);
+          *reinterpret_cast<bf16x8_t*>(TqH_lds + off) = th[c];
+          *reinterpret_cast<bf16x8_t*>(TqL_lds + off) = tl[c];
+        }
+      }
     }
     __syncthreads();
     const int qvalid = min(ATT_QT, nq - qc);
-    for (int q32 = 0; q32 * 32 < qvalid; ++q32) {
-      // S[q][key], dP[q][key] for two 16-query sub-tiles
-      f32x4_t s[2], dp[2];
+    if (wave_active) {
+      for (int q32 = 0; q32 * 32 < qvalid; ++q32) {
+        // S[q][key], dP[q][key] for two 16-query sub-tiles
+        union { bf16x8_t v; unsigned int w[4]; } pf, dsf;
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-        s[sub] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        dp[sub] = s[sub];
-        const int qr = q32 * 32 + 16 * sub + fr;
+        for (int sub = 0; sub < 2; ++sub) {
+          f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = s;
+          const int qr = q32 * 32 + 16 * sub + fr;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int off = qr * 128 + (((fq + 4 * ks) ^ kswz(qr)) << 4);
-          s[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(Q_lds + off), kb[ks], s[sub], 0, 0, 0);
-          dp[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(dO_lds + off), vb[ks], dp[sub], 0, 0, 0);
+          for (int ks = 0; ks < 2; ++ks) {
+            const int off = qr * 128 + (((fq + 4 * ks) ^ kswz(qr)) << 4);
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(Q_lds + off), kb[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(dO_lds + off), vb[ks], dp, 0, 0, 0);
+          }
+#pragma unroll
+          for (int c = 0; c < NSG; ++c) {
+            if (c < nsg) {
+              const int off = c * (ATT_QT * ATT_GROW) + qr * ATT_GROW + ((fq ^ gswz(qr)) << 4);
+              s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(TqH_lds + off), gk[c], s, 0, 0, 0);
+              s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(TqL_lds + off), gk[c], s, 0, 0, 0);
+            }
+          }
+          const int ql0 = q32 * 32 + 16 * sub + 4 * fq;
+          const float4 l4 = *reinterpret_cast<const float4*>(lse_lds + ql0), d4 = *reinterpret_cast<const float4*>(delta_lds + ql0);
+          const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dlv[4] = {d4.x, d4.y, d4.z, d4.w};
+          float pr[4], ds[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pr[r] = __builtin_amdgcn_exp2f(fmaf(s[r], cs, -lv[r]));
+            ds[r] = pr[r] * (dp[r] - dlv[r]) * g.scale;
+          }
+          pf.w[2 * sub] = pack_bf16x2(pr[0], pr[1]); pf.w[2 * sub + 1] = pack_bf16x2(pr[2], pr[3]);
+          dsf.w[2 * sub] = pack_bf16x2(ds[0], ds[1]); dsf.w[2 * sub + 1] = pack_bf16x2(ds[2], ds[3]);
         }
-      }
-      union { bf16x8_t v; unsigned int w[4]; } pf, dsf;
+        // dV^T += dO^T . P ; dK^T += Q^T . dS   (query slot j <-> query 16*(j>>2) + 4*fq + (j&3))
+        const int qrow = q32 * 32 + 4 * fq + (fr >> 2);
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-        float pr[4], ds[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ql = q32 * 32 + 16 * sub + 4 * fq + r;
-          const int qpk = qpos_lds[ql];
-          const int qh = qpk & 0xff, qw = (qpk >> 8) & 0xff, ok = (qpk >> 16) & kp.valid;
-          const float* Tr = T_lds + ql * TLD;
-          const float v = s[sub][r] * g.scale + Tr[kbias_h + qh] + Tr[kbias_w + qw];
-          pr[r] = ok ? __expf(v - lse_lds[ql]) : 0.f;
-          ds[r] = pr[r] * (dp[sub][r] - delta_lds[ql]) * g.scale;
+        for (int u = 0; u < 4; ++u) {
+          const int off = qrow * 128 + (((2 * u + ((fr >> 1) & 1)) ^ kswz(qrow)) << 4) + ((fr & 1) << 3);
+          union { bf16x8_t v; s16x4_t h[2]; } af, bf;
+          af.h[0] = att_tr_read(dO_lds + off); af.h[1] = att_tr_read(dO_lds + off + 16 * 128);
+          bf.h[0] = att_tr_read(Q_lds + off); bf.h[1] = att_tr_read(Q_lds + off + 16 * 128);
+          dv[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, pf.v, dv[u], 0, 0, 0);
+          dk[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf.v, dsf.v, dk[u], 0, 0, 0);
         }
-        pf.w[2 * sub] = pack_bf16x2(pr[0], pr[1]); pf.w[2 * sub + 1] = pack_bf16x2(pr[2], pr[3]);
-        dsf.w[2 * sub] = pack_bf16x2(ds[0], ds[1]); dsf.w[2 * sub + 1] = pack_bf16x2(ds[2], ds[3]);
-      }
-      // dV^T += dO^T . P ; dK^T += Q^T . dS   (query slot j <-> query 16*(j>>2) + 4*fq + (j&3))
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bf16_t* dop = dOt_lds + (16 * u + fr) * QT_LD + q32 * 32 + 4 * fq;
-        const bf16_t* qtp = Qt_lds + (16 * u + fr) * QT_LD + q32 * 32 + 4 * fq;
-        union { bf16x8_t v; u32x2_t h[2]; } af, bf;
-        af.h[0] = *reinterpret_cast<const u32x2_t*>(dop); af.h[1] = *reinterpret_cast<const u32x2_t*>(dop + 16);
-        bf.h[0] = *reinterpret_cast<const u32x2_t*>(qtp); bf.h[1] = *reinterpret_cast<const u32x2_t*>(qtp + 16);
-        dv[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, pf.v, dv[u], 0, 0, 0);
-        dk[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf.v, dsf.v, dk[u], 0, 0, 0);
       }
     }
   }
@@ -385,6 +413,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
 
 int attn_fill_geom(AttnGeom* g, int64_t G, int64_t Sh, int64_t Sw, int64_t heads, int64_t hd, int64_t ws,
                    int64_t Lh, int64_t Lw, int64_t NT, float scale, const char* who);
+int attn_query_tiles(const AttnGeom& g);
 
 extern "C" int mfnet_attn_bwd(const void* qkv, const float* qkv_bias, const void* tbl, const void* tblT,
                               const void* out, const void* dout, const float* lse, void* dqkv, int64_t G,
@@ -400,23 +429,25 @@ extern "C" int mfnet_attn_bwd(const void* qkv, const float* qkv_bias, const void
   p.out = (const bf16_t*)out; p.dout = (const bf16_t*)dout; p.lse = lse; p.dqkv = (bf16_t*)dqkv;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { mfnet_set_error("attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MFNET_ERR_HIP; }
     attr_set = true;
   }
-  const int maxq = p.g.ws > 0 ? p.g.ws * p.g.ws : p.g.Sh * p.g.Sw;
-  dim3 grid((unsigned)ceil_div64(maxq, ATT_QT), (unsigned)heads, (unsigned)(G * p.g.nWh * p.g.nWw));
-  MF_CHECK_ARG(grid.z <= 65535 && grid.y <= 65535, "attn_bwd: grid too large");
+  const int nsg = (p.g.KH + p.g.KW + 31) / 32;       // <= 2 because NT <= 96
   const size_t TL = (size_t)ATT_QT * (p.g.NT + 4) * 4;
-  const size_t nGrows = 16 * (size_t)((p.g.KH + p.g.KW + 15) / 16);
-  MF_CHECK_ARG(nGrows <= 64 && TL <= 2 * (size_t)ATT_KC * ATT_HD * 2, "attn_bwd: key grid too large for the dT staging");
-  const size_t lds_dq = 2 * (size_t)ATT_KC * ATT_HD * 2 + (size_t)ATT_HD * ATT_VT_LD * 2 + ATT_KC * 4 + TL + nGrows * ATT_VT_LD * 2;
-  const size_t lds_dkv = 2 * (size_t)ATT_QT * ATT_HD * 2 + 2 * (size_t)ATT_HD * QT_LD * 2 + 3 * ATT_QT * 4 + TL;
+  const size_t lds_dq = (size_t)att_region_a(p.g.NT) + (size_t)nsg * ATT_KC * ATT_GROW;
+  const size_t lds_dkv = 2 * (size_t)ATT_QT * ATT_HD * 2 + 2 * ATT_QT * 4 + 2 * (size_t)nsg * ATT_QT * ATT_GROW + TL;
   // the two kernels write disjoint column ranges of dqkv (q | k,v); window mode leaves nothing unwritten
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), lds_dq, stream, p);
+  dim3 grid_q((unsigned)attn_query_tiles(p.g), (unsigned)heads, (unsigned)G);
+  MF_CHECK_ARG(grid_q.z <= 65535 && grid_q.y <= 65535, "attn_bwd: grid too large");
+  if (nsg <= 1) hipLaunchKernelGGL(attn_bwd_dq_kernel<1>, grid_q, dim3(256), lds_dq, stream, p);
+  else hipLaunchKernelGGL(attn_bwd_dq_kernel<2>, grid_q, dim3(256), lds_dq, stream, p);
   MF_LAUNCH_CHECK("attn_bwd_dq");
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), lds_dkv, stream, p);
+  if (nsg <= 1) hipLaunchKernelGGL(attn_bwd_dkv_kernel<1>, grid_q, dim3(256), lds_dkv, stream, p);
+  else hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, grid_q, dim3(256), lds_dkv, stream, p);
   MF_LAUNCH_CHECK("attn_bwd_dkv");
   return MFNET_OK;
 }
