@@ -32,7 +32,7 @@ struct AttnBwdParams {
 // bias as the indicator product G.T'^T. The two transposed operands of this kernel, K^T (dQ^T += K^T.dS^T) and
 // G^T (dT'^T += G^T.dS^T), are read from the SAME row-major images with ds_read_b64_tr_b16.
 template <int NSG>
-__global__ __launch_bounds__(256, NSG == 1 ? 3 : 2) void attn_bwd_dq_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(256, NSG == 1 ? 3 : (NSG == 2 ? 2 : 1)) void attn_bwd_dq_kernel(const AttnBwdParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const AttnGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256, NSG == 1 ? 3 : 2) void attn_bwd_dq_kernel(cons
 // dO are staged row-major only; their transposes come from ds_read_b64_tr_b16. The rel-pos bias is the
 // product T'.G^T: T' (per query, hi + lo bf16 rows staged in LDS) times this lane's key indicator (registers).
 template <int NSG>
-__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(256, NSG == 4 ? 2 : 3) void attn_bwd_dkv_kernel(const AttnBwdParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const AttnGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -423,31 +423,35 @@ extern "C" int mfnet_attn_bwd(const void* qkv, const float* qkv_bias, const void
   AttnBwdParams p;
   int rc = attn_fill_geom(&p.g, G, Sh, Sw, heads, hd, ws, Lh, Lw, NT, scale, "attn_bwd");
   if (rc) return rc;
-  if (NT > 96) { mfnet_set_error("attn_bwd: NT=%lld > 96 (token grids above 24x24) not supported yet", (long long)NT); return MFNET_ERR_UNSUPPORTED; }
-  MF_CHECK_ARG(p.g.KH < 256 && p.g.KW < 256, "attn_bwd: key grid too large");
+  MF_CHECK_ARG(p.g.KH + p.g.KW <= 128, "attn_bwd: key grid %dx%d too large (KH + KW <= 128)", p.g.KH, p.g.KW);
   p.qkv = (const bf16_t*)qkv; p.qkv_bias = qkv_bias; p.tbl = (const bf16_t*)tbl; p.tblT = (const bf16_t*)tblT;
   p.out = (const bf16_t*)out; p.dout = (const bf16_t*)dout; p.lse = lse; p.dqkv = (bf16_t*)dqkv;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { mfnet_set_error("attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MFNET_ERR_HIP; }
     attr_set = true;
   }
-  const int nsg = (p.g.KH + p.g.KW + 31) / 32;       // <= 2 because NT <= 96
+  const int nsg = (p.g.KH + p.g.KW + 31) / 32;
   const size_t TL = (size_t)ATT_QT * (p.g.NT + 4) * 4;
   const size_t lds_dq = (size_t)att_region_a(p.g.NT) + (size_t)nsg * ATT_KC * ATT_GROW;
   const size_t lds_dkv = 2 * (size_t)ATT_QT * ATT_HD * 2 + 2 * ATT_QT * 4 + 2 * (size_t)nsg * ATT_QT * ATT_GROW + TL;
+  MF_CHECK_ARG(lds_dq <= 160 * 1024 && lds_dkv <= 160 * 1024, "attn_bwd: LDS demand too large");
   // the two kernels write disjoint column ranges of dqkv (q | k,v); window mode leaves nothing unwritten
   dim3 grid_q((unsigned)attn_query_tiles(p.g), (unsigned)heads, (unsigned)G);
   MF_CHECK_ARG(grid_q.z <= 65535 && grid_q.y <= 65535, "attn_bwd: grid too large");
   if (nsg <= 1) hipLaunchKernelGGL(attn_bwd_dq_kernel<1>, grid_q, dim3(256), lds_dq, stream, p);
-  else hipLaunchKernelGGL(attn_bwd_dq_kernel<2>, grid_q, dim3(256), lds_dq, stream, p);
+  else if (nsg == 2) hipLaunchKernelGGL(attn_bwd_dq_kernel<2>, grid_q, dim3(256), lds_dq, stream, p);
+  else hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, grid_q, dim3(256), lds_dq, stream, p);
   MF_LAUNCH_CHECK("attn_bwd_dq");
   if (nsg <= 1) hipLaunchKernelGGL(attn_bwd_dkv_kernel<1>, grid_q, dim3(256), lds_dkv, stream, p);
-  else hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, grid_q, dim3(256), lds_dkv, stream, p);
+  else if (nsg == 2) hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, grid_q, dim3(256), lds_dkv, stream, p);
+  else hipLaunchKernelGGL(attn_bwd_dkv_kernel<4>, grid_q, dim3(256), lds_dkv, stream, p);
   MF_LAUNCH_CHECK("attn_bwd_dkv");
   return MFNET_OK;
 }

@@ -220,7 +220,8 @@ def _rel_tables(rel_h, rel_w, k):
     return build_rel_table(rel_h, rel_w, k, k)
 
 
-@pytest.mark.parametrize("S,ws,heads,G", [(16, 14, 2, 2), (16, 0, 2, 2), (20, 14, 3, 1), (20, 0, 1, 2), (16, 14, 12, 4)])
+@pytest.mark.parametrize("S,ws,heads,G", [(16, 14, 2, 2), (16, 0, 2, 2), (20, 14, 3, 1), (20, 0, 1, 2), (16, 14, 12, 4),
+                                          (32, 0, 1, 1), (64, 14, 1, 1), (64, 0, 1, 1)])   # 2 and 4 slot groups; 1024-px grid
 def test_attention_fwd_bwd(ops, S, ws, heads, G):
     D = heads * 64
     qkv = rnd(G * S * S, 3 * D, seed=1, scale=1.5).to(torch.bfloat16)
