@@ -59,8 +59,6 @@ __device__ __forceinline__ int kswz(int row) { return row & 7; }   // 16-B chunk
 __device__ __forceinline__ int gswz(int row) { return (row >> 2) & 3; }   // same for the 64-B indicator rows
 
 #define ATT_GROW 64        // bytes per key row of one 32-slot indicator image
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr_t;
 
 // LDS bytes shared by the K / V images (key loop) and the T table (before it)
 __host__ __device__ inline int att_region_a(int NT) {

@@ -39,6 +39,8 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragme
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // MFMA 16x16 C/D fragment
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;                 // result of ds_read_b64_tr_b16
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr_t;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((unsigned int)v) << 16);

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const ColRedParams p) {
     ga = reinterpret_cast<const float4*>(p.gamma)[cg]; be = reinterpret_cast<const float4*>(p.beta)[cg];
   }
   if (rl < nrl) {
+#pragma unroll 4
     for (int64_t r = r0 + rl; r < r1; r += nrl) {
       const int64_t row = g * p.P + r;
       const float4 a = ld4(p.a, p.a_dt, row * C4 + cg);
@@ -117,7 +118,10 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const ColRedParams p) {
 static int launch_colreduce(ColRedParams& p, int64_t G, hipStream_t stream, const char* who) {
   MF_CHECK_ARG(p.C > 0 && p.C % 4 == 0 && p.C <= 1024 && 256 % (p.C / 4) == 0, "%s: C=%d must be a multiple of 4 dividing 1024", who, p.C);
   MF_CHECK_ARG(G > 0 && G < 65536 && p.P > 0, "%s: bad group geometry", who);
+  // at most 128 workgroups add into one output row: the float atomics of the finish serialise per address
+  // (512 per address cost more than streaming the 17 MB map)
   int64_t splits = ceil_div64(512, G);
+  if (splits > 128) splits = 128;
   int64_t rpb = ceil_div64(p.P, splits);
   const int nrl = 256 / (p.C / 4);
   if (rpb < 8 * nrl) rpb = 8 * nrl;

@@ -163,13 +163,95 @@ __global__ __launch_bounds__(256) void skinny_tn_reduce_kernel(const float* __re
   }
 }
 
+// MFMA version of the two-stage path: out[c][j] = sum_m y[m][c] * u[m][j] as (y^T).(u) with the rows m as the
+// contraction index. Each wave owns 64 columns of y; per 32-row step it copies its [32][64] bf16 slab into a
+// wave-private LDS image (row-major, XOR-swizzled) and takes the TRANSPOSED A fragments from it with
+// ds_read_b64_tr_b16; the B operand is u converted on the fly, split hi + lo in bf16 (two MFMAs into one
+// accumulator), so the fp32 factor keeps ~16 mantissa bits. No barrier: LDS is never shared between waves.
+// k-slot j of lane group fq <-> row 16*(j>>2) + 4*fq + (j&3) of the step (same permutation on both operands).
+template <int R>
+__global__ __launch_bounds__(256) void skinny_tn_mfma_kernel(const bf16_t* __restrict__ Y, int64_t ldy,
+                                                             const float* __restrict__ U, int64_t ldu, int64_t M, int C,
+                                                             int64_t rows_per_block, float* __restrict__ partial, int64_t group_rows) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4][2][32 * 128];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  Y += (int64_t)blockIdx.z * group_rows * ldy;
+  U += (int64_t)blockIdx.z * group_rows * ldu;
+  partial += ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * C * R;
+  const int cw = (blockIdx.x * 4 + wave) * 64;                   // first column of this wave
+  if (cw >= C) return;
+  const int64_t r_begin = (int64_t)blockIdx.y * rows_per_block;
+  int64_t r_end = r_begin + rows_per_block;
+  if (r_end > M) r_end = M;
+  if (r_begin >= r_end) return;
+  // staging: lane copies 16-B chunk (lane & 7) of rows (lane >> 3) + 8*i, i < 4
+  const int srow = lane >> 3, sch = lane & 7;
+  const int scol = min(cw + sch * 8, C - 8);                      // chunks beyond C re-read the last one (never stored)
+  const int ucol = fr < R ? fr : 0;
+  f32x4_t acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  u32x4_t yv[4];
+  float uv[8];
+  auto issue = [&](int64_t m0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int64_t m = m0 + srow + 8 * i;
+      m = m < r_end ? m : r_end - 1;
+      yv[i] = *reinterpret_cast<const u32x4_t*>(Y + m * ldy + scol);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t m = m0 + 16 * (j >> 2) + 4 * fq + (j & 3);
+      uv[j] = (m < r_end && fr < R) ? U[(m < r_end ? m : r_end - 1) * ldu + ucol] : 0.f;
+    }
+  };
+  issue(r_begin);
+  int buf = 0;
+  for (int64_t m0 = r_begin; m0 < r_end; m0 += 32, buf ^= 1) {
+    unsigned char* img = lds[wave][buf];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = srow + 8 * i;
+      *reinterpret_cast<u32x4_t*>(img + row * 128 + ((sch ^ (row & 7)) << 4)) = yv[i];
+    }
+    union { bf16x8_t v; unsigned int w[4]; } uh, ul;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uh.w[i] = pack_bf16x2(uv[2 * i], uv[2 * i + 1]);
+      ul.w[i] = pack_bf16x2(uv[2 * i] - bf16_lo(uh.w[i]), uv[2 * i + 1] - bf16_hi(uh.w[i]));
+    }
+    if (m0 + 32 < r_end) issue(m0 + 32);
+    const int trow = 4 * fq + (fr >> 2);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const unsigned char* a = img + trow * 128 + (((2 * t + ((fr >> 1) & 1)) ^ (trow & 7)) << 4) + ((fr & 1) << 3);
+      union { bf16x8_t v; s16x4_t h[2]; } yf;
+      yf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)a);
+      yf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(a + 16 * 128));
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf.v, uh.v, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf.v, ul.v, acc[t], 0, 0, 0);
+    }
+  }
+  // acc[t][r] = out[cw + 16 t + 4 fq + r][fr]
+  if (fr < R) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = cw + 16 * t + 4 * fq + r;
+        if (c < C) partial[(int64_t)c * R + fr] = acc[t][r];
+      }
+  }
+}
+
 static void skinny_tn_geometry(int64_t M, int64_t C, int64_t* strips, int64_t* splits, int64_t* rpb) {
-  *strips = ceil_div64(C, 512);
-  int64_t sp = ceil_div64(128, *strips);              // ~128 workgroups per group (two groups per launch)
-  if (sp > 32) sp = 32;                               // the second stage sums at most 32 partials per output
-  int64_t r = ceil_div64(M, sp);
+  *strips = ceil_div64(C, 256);                       // four waves x 64 columns (MFMA path); the scalar path uses strips of 512
+  int64_t r = ceil_div64(M, 32);                      // the second stage sums at most 32 partials per output
   if (r < 64) r = 64;
-  r = ceil_div64(r, 4) * 4;
+  r = ceil_div64(r, 32) * 32;
   *rpb = r;
   *splits = ceil_div64(M, r);
 }
@@ -217,10 +299,18 @@ extern "C" int mfnet_skinny_tn(const void* Y, int64_t ldy, const float* U, int64
     MF_CHECK_ARG(workspace_floats >= n_groups * splits * C * R, "skinny_tn: workspace too small (%lld < %lld floats)", (long long)workspace_floats, (long long)(n_groups * splits * C * R));
     partial = workspace;
   }
-  dim3 grid((unsigned)strips, (unsigned)splits, (unsigned)n_groups), block(256);
+  dim3 block(256);
+  if (partial) {
+    dim3 grid((unsigned)strips, (unsigned)splits, (unsigned)n_groups);
+#define SKTNM(RR) hipLaunchKernelGGL((skinny_tn_mfma_kernel<RR>), grid, block, 0, stream, (const bf16_t*)Y, ldy, U, ldu, M, (int)C, rpb, partial, M)
+    if (R == 4) SKTNM(4); else if (R == 8) SKTNM(8); else SKTNM(16);
+#undef SKTNM
+  } else {
+    dim3 grid((unsigned)ceil_div64(C, 512), (unsigned)splits, (unsigned)n_groups);
 #define SKTN(RR) hipLaunchKernelGGL((skinny_tn_kernel<RR>), grid, block, 0, stream, (const bf16_t*)Y, ldy, U, ldu, out, M, (int)C, rpb, transposed, scale, partial, M, out_group_stride)
-  if (R == 4) SKTN(4); else if (R == 8) SKTN(8); else SKTN(16);
+    if (R == 4) SKTN(4); else if (R == 8) SKTN(8); else SKTN(16);
 #undef SKTN
+  }
   if (partial) {
     int64_t g = ceil_div64(C * R, 256);
     hipLaunchKernelGGL(skinny_tn_reduce_kernel, dim3((unsigned)g, (unsigned)n_groups), dim3(256), 0, stream, partial, out, (int)C, R, (int)splits, transposed, scale, out_group_stride);
