@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Turn two rocprofv3 counter passes into per-launch HBM traffic of one kernel.
 
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-roofline
-    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-roofline
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-roofline --eager
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-roofline --eager
     python tools/pmc_traffic.py /tmp/pmc_f/f_counter_collection.csv /tmp/pmc_w/w_counter_collection.csv gemm_bf16_kernel profiles/rNN_gemm_pmc.json
 
 Corrections (MI355X_MICROARCH.md, "HBM"): the counters are in KiB; on gfx950 FETCH_SIZE reports half of the
@@ -25,8 +25,8 @@ def per_kernel(path, counter):
 
 def main():
     fpath, wpath, kern, out = sys.argv[1:5]
-    f = {k: v for k, v in per_kernel(fpath, "FETCH_SIZE").items() if k.startswith(kern)}
-    w = {k: v for k, v in per_kernel(wpath, "WRITE_SIZE").items() if k.startswith(kern)}
+    f = {k: v for k, v in per_kernel(fpath, "FETCH_SIZE").items() if kern in k}
+    w = {k: v for k, v in per_kernel(wpath, "WRITE_SIZE").items() if kern in k}
     nf, sf = map(sum, zip(*f.values()))
     nw, sw = map(sum, zip(*w.values()))
     d = {"kernel": kern, "dispatches": nf, "FETCH_SIZE_KB_per_launch_raw": sf / nf, "WRITE_SIZE_KB_per_launch_raw": sw / nw,
