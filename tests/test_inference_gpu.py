@@ -141,6 +141,73 @@ def test_train_engine_graph_mode_matches_eager():
     assert losses[True][-1] < losses[True][0]
 
 
+def test_engine_gradients_equal_plain_autograd_and_bank_is_never_stale():
+    """The engine's step-scoped plumbing (parameter bank, direct gradient delivery, zero arena) changes no
+    arithmetic: the flat gradient buffer after forward_backward equals the gradients plain autograd returns for
+    the same model without an engine; and a forward outside the engine after optimizer steps sees the UPDATED
+    weights (the bank only serves derived operands inside a step)."""
+    from ssrs_amd import ops
+    from ssrs_amd.trainer import TrainEngine, trainable_tensors
+    rgb, dsm, tgt = [t.cuda() for t in detfill.tiles("bank", 2, 256, 6)]
+    w = torch.ones(6, device="cuda")
+
+    def make():
+        m = _tiny()
+        m.load_state_dict(detfill.fill_state_dict(m.state_dict(), "bank/"))
+        m = m.cuda().train()
+        m.decoder.segmentation_head[1].p = 0.0
+        return m
+    def plain_grads():
+        m_ref = make()
+        named, _ = trainable_tensors(m_ref)
+        out = m_ref(rgb, dsm, mode="Train").contiguous()
+        acc, _ = ops.ce_loss_fwd(out, tgt, w, -100)
+        out.backward(ops.ce_loss_bwd(out, tgt, acc, w, -100, 1.0))
+        return {n: p.grad.clone() for n, p in named}
+    # two plain runs differ by the float-atomic order of the BatchNorm / split reductions, amplified by the
+    # decoder's ReLU6 / max-pool switches (DESIGN.md section 7): that run-to-run noise is the yardstick
+    ref, ref2 = plain_grads(), plain_grads()
+    m = make()
+    eng = TrainEngine(m, lr=0.01, momentum=0.9, weight_decay=5e-4, class_weight=w)
+    for _ in range(2):                                # second pass runs on the bank's persistent tensors + arena
+        eng.zero_grad()
+        eng.forward_backward(rgb, dsm, tgt)
+        for n, p in zip(eng.names, eng.params):
+            g, r = p.grad, ref[n]
+            noise = (ref2[n] - r).abs().max().item()
+            assert (g - r).abs().max().item() <= 10 * noise + 1e-3 * r.abs().max().item() + 1e-7, (n, noise)
+    for _ in range(2):
+        eng.step(rgb, dsm, tgt)
+    # outside a step every derived operand is rebuilt from the CURRENT weights ...
+    from ssrs_amd import decoder_ops as D
+    from ssrs_amd.bank import ParamBank
+    from ssrs_amd.vit import _mix_V
+    assert ParamBank.active is None and ops.ZeroArena.current is None
+    w3 = m.decoder.b4.attn.local1[0].weight
+    lin = m.image_encoder.blocks[0].mlp.lin1
+    fresh_w3 = w3.detach().permute(0, 2, 3, 1).reshape(w3.shape[0], -1).to(torch.bfloat16)
+    fresh_V = torch.cat([lin.lora_Bx.detach(), lin.lora_By.detach()], 1)
+    assert torch.equal(D._wb_w3(w3), fresh_w3) and torch.equal(_mix_V(lin), fresh_V)
+    # ... inside a step the bank serves its persistent tensors, re-filled from the current weights on entry
+    key_w3 = ("w3", w3.data_ptr())
+    stale = eng.bank.entries[key_w3][0].clone()                     # filled at the start of the LAST step
+    assert not torch.equal(stale, fresh_w3)                         # the SGD update after it did move the weight
+    with eng.bank:
+        assert D._wb_w3(w3).data_ptr() == eng.bank.entries[key_w3][0].data_ptr()
+        assert torch.equal(D._wb_w3(w3), fresh_w3) and torch.equal(_mix_V(lin), fresh_V)
+    # and a forward outside the engine agrees with a fresh model holding the same state (up to the float-atomic
+    # order of the SE pools, which flips single bf16 ulps in the fused features)
+    m.eval()
+    with torch.no_grad():
+        after = m(rgb, dsm)
+    m2 = make()
+    m2.load_state_dict(m.state_dict())
+    m2.eval()
+    with torch.no_grad():
+        fresh = m2(rgb, dsm)
+    assert (after - fresh).abs().max().item() <= 3e-2 * fresh.abs().max().item()
+
+
 def test_confusion_and_metrics():
     from ssrs_amd import ops
     from ssrs_amd.inference import metrics_from_confusion

@@ -307,3 +307,32 @@ def test_gemm_tn_split_k(ops, M, N, K):
     ref = dy.double().t() @ x.double()
     assert got.shape == (N, K)
     assert rel_err(got, ref) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ batched strided copies
+def test_gather_segments(ops):
+    """mfnet_gather_segments: permuted / sliced / broadcast sources, sliced destinations, fp32 assign and
+    accumulate, bf16 assign, and more segments than fit one launch (48)."""
+    base = rnd(7, 5, 3, 4, seed=1)
+    mats = [rnd(33, 17, seed=10 + i) for i in range(60)]
+    pairs, refs = [], []
+    d0 = torch.zeros(4, 3, 5, 7, device="cuda")
+    pairs.append((d0, base.permute(3, 2, 1, 0))); refs.append((d0, base.permute(3, 2, 1, 0).clone()))
+    d1 = torch.zeros(40, 20, device="cuda")
+    pairs.append((d1[3:36, 2:19], mats[0]))
+    r1 = torch.zeros(40, 20, device="cuda"); r1[3:36, 2:19] = mats[0]
+    refs.append((d1, r1))
+    d2 = torch.zeros(4, 17, device="cuda")
+    pairs.append((d2, mats[1][5].expand(4, 17))); refs.append((d2, mats[1][5].expand(4, 17).clone()))
+    for i in range(2, 60):
+        d = torch.zeros(17, 33, device="cuda")
+        pairs.append((d, mats[i].t())); refs.append((d, mats[i].t().clone()))
+    ops.gather(pairs)
+    for d, r in refs:
+        assert torch.equal(d, r)
+    ops.gather(pairs, accumulate=True)
+    for d, r in refs:
+        assert torch.equal(d, 2 * r)
+    db = torch.zeros(17, 33, dtype=torch.bfloat16, device="cuda")
+    ops.gather([(db, mats[3].t())])
+    assert torch.equal(db, mats[3].t().to(torch.bfloat16))
