@@ -127,6 +127,14 @@ int mfnet_im2col3x3(const void* x, void* cols, int64_t G, int64_t H, int64_t W, 
 int mfnet_col2im3x3(const void* dcols, float* dx, int64_t G, int64_t H, int64_t W, int64_t C, hipStream_t stream);
 int mfnet_transpose_bf16(const void* x, int64_t ld, void* y, int64_t M, int64_t N, int64_t Mp, hipStream_t stream);
 /* out[i] (= | +=) scale * sum_s partial[s*n + i], n % 4 == 0: second stage of the split-K weight gradients. */
+/* Weight-gradient GEMM out[n][k] = sum_m dy[m][n] * x[m][k] on the row-major activations themselves (bf16, row
+ * strides ldy / ldx), fp32 result: the wgrad of every trainable conv / linear of the decoder, FPN and adapters
+ * (what autograd's conv / linear backward computes for unetformer_mmsam.py:43-84, adapter.py:17-25). The row range
+ * is cut into `splits` (mfnet_gemm_tn_splits gives a good count); split s writes its partial [N][ldo] tile at
+ * out + s*N*ldo, to be summed by mfnet_reduce_splits (splits == 1: out is the result). */
+int mfnet_gemm_tn_bf16(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t M, int64_t N, int64_t K,
+                       float* out, int64_t ldo, int splits, hipStream_t stream);
+int64_t mfnet_gemm_tn_splits(int64_t M, int64_t N, int64_t K);
 int mfnet_reduce_splits(const float* partial, float* out, int64_t n, int splits, float scale, int accumulate, hipStream_t stream);
 
 /* Strided gather of n small fp32 tensors in one launch (per 48 segments). desc is a HOST array of n x 14

@@ -318,3 +318,113 @@ extern "C" int mfnet_skinny_tn(const void* Y, int64_t ldy, const float* U, int64
   MF_LAUNCH_CHECK("skinny_tn");
   return MFNET_OK;
 }
+
+// =====================================================================================================
+// Weight-gradient GEMM  out[n][k] = sum_m dy[m][n] * x[m][k]  (both operands bf16 row-major with the
+// contraction index m leading - the layout every activation already has), fp32 out. Each WAVE owns a 64 x 64
+// output tile and keeps wave-private row-major LDS slabs of its dy and x columns ([32 rows][64] each, XOR-
+// swizzled): BOTH MFMA operands are "transposed" reads (ds_read_b64_tr_b16), so no transposed copy of an
+// activation is ever written to HBM (the first version transposed both operands first: 70 launches and
+// 0.8 ms per step). LDS operations of one wave execute in order, so the slab is single-buffered and the kernel
+// has no barrier; the next step's global loads are in flight while the current one multiplies.
+// The row range is cut into `splits`; split s stores its partial tile into out + s*N*ldo (mfnet_reduce_splits
+// sums them), exactly like the split-K mode of mfnet_gemm_bf16.
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ DY, int64_t ldy, const bf16_t* __restrict__ X, int64_t ldx,
+                                                      int64_t M, int N, int K, int64_t rows_per_split, float* __restrict__ out, int64_t ldo) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4][2][32 * 128];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int n0 = blockIdx.y * 64;
+  const int k0 = (blockIdx.x * 4 + wave) * 64;
+  if (k0 >= K) return;
+  const int64_t r_begin = (int64_t)blockIdx.z * rows_per_split;
+  int64_t r_end = r_begin + rows_per_split;
+  if (r_end > M) r_end = M;
+  out += (int64_t)blockIdx.z * N * ldo;
+  unsigned char* img_a = lds[wave][0];
+  unsigned char* img_b = lds[wave][1];
+  const int srow = lane >> 3, sch = lane & 7;
+  const int acol = min(n0 + sch * 8, N - 8), bcol = min(k0 + sch * 8, K - 8);   // chunks past the edge re-read the last one
+  f32x4_t acc[4][4];      // [n tile][k tile]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  u32x4_t av[4], bv[4];
+  auto issue = [&](int64_t m0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = m0 + srow + 8 * i;
+      const int64_t mc = m < r_end ? m : r_end - 1;
+      av[i] = *reinterpret_cast<const u32x4_t*>(DY + mc * ldy + acol);
+      bv[i] = *reinterpret_cast<const u32x4_t*>(X + mc * ldx + bcol);
+      if (m >= r_end) av[i] = (u32x4_t){0u, 0u, 0u, 0u};          // rows past the split contribute nothing
+    }
+  };
+  if (r_begin < r_end) issue(r_begin);
+  for (int64_t m0 = r_begin; m0 < r_end; m0 += 32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = srow + 8 * i;
+      const int off = row * 128 + ((sch ^ (row & 7)) << 4);
+      *reinterpret_cast<u32x4_t*>(img_a + off) = av[i];
+      *reinterpret_cast<u32x4_t*>(img_b + off) = bv[i];
+    }
+    if (m0 + 32 < r_end) issue(m0 + 32);
+    // k-slot j of lane group fq <-> row 16*(j>>2) + 4*fq + (j&3) of the step, on both operands
+    const int trow = 4 * fq + (fr >> 2);
+    bf16x8_t af[4], bf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int off = trow * 128 + (((2 * t + ((fr >> 1) & 1)) ^ (trow & 7)) << 4) + ((fr & 1) << 3);
+      union { bf16x8_t v; s16x4_t h[2]; } a, b;
+      a.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(img_a + off));
+      a.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(img_a + off + 16 * 128));
+      b.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(img_b + off));
+      b.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(img_b + off + 16 * 128));
+      af[t] = a.v; bf[t] = b.v;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+  }
+  // acc[a][b][r] = out[n0 + 16 a + 4 fq + r][k0 + 16 b + fr]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 16 * a + 4 * fq + r;
+      if (n >= N) continue;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int k = k0 + 16 * b + fr;
+        if (k < K) out[(int64_t)n * ldo + k] = acc[a][b][r];
+      }
+    }
+}
+
+extern "C" int64_t mfnet_gemm_tn_splits(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 1;
+  const int64_t tiles = ceil_div64(N, 64) * ceil_div64(K, 256);
+  int64_t s = ceil_div64(768, tiles);                  // ~3 workgroups per CU
+  const int64_t smax = ceil_div64(M, 512);             // at least 16 steps of 32 rows per split (partials cost traffic too)
+  if (s > smax) s = smax;
+  if (s > 256) s = 256;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" int mfnet_gemm_tn_bf16(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t M, int64_t N, int64_t K,
+                                  float* out, int64_t ldo, int splits, hipStream_t stream) {
+  MF_CHECK_ARG(dy && x && out, "gemm_tn: null pointer");
+  MF_CHECK_ARG(M > 0 && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0, "gemm_tn: N=%lld and K=%lld must be multiples of 8", (long long)N, (long long)K);
+  MF_CHECK_ARG(ldy % 8 == 0 && ldx % 8 == 0 && ldy >= N && ldx >= K && ldo >= K, "gemm_tn: bad leading dimensions");
+  MF_CHECK_ARG(((uintptr_t)dy | (uintptr_t)x) % 16 == 0, "gemm_tn: operands must be 16-byte aligned");
+  MF_CHECK_ARG(splits >= 1 && splits <= 65535 && N < (1ll << 31) && K < (1ll << 31), "gemm_tn: bad splits / shape");
+  int64_t rps = ceil_div64(ceil_div64(M, splits), 32) * 32;
+  dim3 grid((unsigned)ceil_div64(K, 256), (unsigned)ceil_div64(N, 64), (unsigned)splits);
+  MF_CHECK_ARG(grid.y <= 65535, "gemm_tn: N too large");
+  hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, stream, (const bf16_t*)dy, ldy, (const bf16_t*)x, ldx, M, (int)N, (int)K, rps, out, ldo);
+  MF_LAUNCH_CHECK("gemm_tn");
+  return MFNET_OK;
+}

@@ -377,16 +377,20 @@ def transpose_pad(x, mult=64):
 
 
 def gemm_tn(dy, x):
-    """dW[n,k] = sum_m dy[m,n] x[m,k]  (fp32 [N,K]); both bf16 row-major with M leading. The reduction
-    runs over the rows (pixels / tokens), so it is cut into K-splits until ~512 workgroups exist."""
-    a, b = transpose_pad(dy), transpose_pad(x)
-    tiles = ((a.shape[0] + 127) // 128) * ((b.shape[0] + 127) // 128)
-    nt = a.shape[1] // 64
-    splits = max(1, min(nt // 4, 512 // tiles))
+    """dW[n,k] = sum_m dy[m,n] x[m,k]  (fp32 [N,K]); both bf16 row-major with M leading (views with a row
+    stride are fine). The reduction runs over the rows (pixels / tokens): it is cut into splits whose partial
+    tiles one small kernel sums."""
+    _chk(dy, x)
+    assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.stride(-1) == 1 and x.stride(-1) == 1
+    d2, M, N, ldy = _rows2d(dy)
+    x2, M2, K, ldx = _rows2d(x)
+    assert M == M2
+    splits = int(_lib.lib().mfnet_gemm_tn_splits(M, N, K))
+    part = torch.empty((splits, N, K), dtype=torch.float32, device=dy.device)
+    call("mfnet_gemm_tn_bf16", d2.data_ptr(), ldy, x2.data_ptr(), ldx, M, N, K, part.data_ptr(), K, splits, _stream(dy))
     if splits == 1:
-        return gemm(a, b, out_dtype=torch.float32)
-    part = gemm(a, b, out_dtype=torch.float32, k_splits=splits)
-    out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
+        return part[0]
+    out = torch.empty((N, K), dtype=torch.float32, device=dy.device)
     call("mfnet_reduce_splits", part.data_ptr(), out.data_ptr(), out.numel(), splits, 1.0, 0, _stream(part))
     return out
 

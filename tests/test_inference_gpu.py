@@ -164,18 +164,36 @@ def test_engine_gradients_equal_plain_autograd_and_bank_is_never_stale():
         acc, _ = ops.ce_loss_fwd(out, tgt, w, -100)
         out.backward(ops.ce_loss_bwd(out, tgt, acc, w, -100, 1.0))
         return {n: p.grad.clone() for n, p in named}
-    # two plain runs differ by the float-atomic order of the BatchNorm / split reductions, amplified by the
-    # decoder's ReLU6 / max-pool switches: that run-to-run noise is the yardstick
-    ref, ref2 = plain_grads(), plain_grads()
+    # Run-to-run, plain autograd itself moves small gradients (scalars like lora_wy, biases in front of a BatchNorm
+    # whose true gradient is 0) by 10-30 % on this 2-tile random model: the float-atomic order of the BatchNorm /
+    # pool reductions flips ReLU6 / max-pool switches. So the whole model is compared as one
+    # vector ...
+    ref = plain_grads()
     m = make()
     eng = TrainEngine(m, lr=0.01, momentum=0.9, weight_decay=5e-4, class_weight=w)
+    flat_ref = torch.cat([ref[n].reshape(-1) for n in eng.names])
     for _ in range(2):                                # second pass runs on the bank's persistent tensors + arena
         eng.zero_grad()
         eng.forward_backward(rgb, dsm, tgt)
+        flat = torch.cat([p.grad.reshape(-1) for p in eng.params])
+        cos = torch.nn.functional.cosine_similarity(flat, flat_ref, dim=0).item()
+        assert cos > 0.98 and abs(flat.norm().item() / flat_ref.norm().item() - 1) < 5e-2, cos
+    # ... and the plumbing is pinned exactly where the map is smooth.
+    # The encoder alone is a smooth map (no BatchNorm / ReLU6 / max-pool switches): with a fixed upstream gradient
+    # the delivered gradients must equal plain autograd's to reduction-order noise.
+    up = torch.from_numpy(detfill.uniform("bank/up", (4, 16, 16, 256))).cuda() * 1e-2
+    m_plain = make()
+    m_plain.image_encoder.forward_stacked(rgb, dsm).backward(up)
+    plain = {n: p.grad for n, p in m_plain.named_parameters() if p.grad is not None}
+    assert len(plain) == sum(1 for n in eng.names if ".image_encoder." in "." + n)
+    for _ in range(2):
+        eng.zero_grad()
+        with eng.bank, eng.arena:
+            m.image_encoder.forward_stacked(rgb, dsm).backward(up)
         for n, p in zip(eng.names, eng.params):
-            g, r = p.grad, ref[n]
-            noise = (ref2[n] - r).abs().max().item()
-            assert (g - r).abs().max().item() <= 10 * noise + 1e-3 * r.abs().max().item() + 1e-7, (n, noise)
+            if n in plain:
+                r = plain[n]
+                assert (p.grad - r).abs().max().item() <= 2e-4 * r.abs().max().item() + 1e-9, n
     for _ in range(2):
         eng.step(rgb, dsm, tgt)
     # outside a step every derived operand is rebuilt from the CURRENT weights ...

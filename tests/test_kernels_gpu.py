@@ -298,9 +298,10 @@ def test_tile_accumulate_argmax_minmax(ops):
     assert rel_err(y, (x - x.min()) / (x.max() - x.min())) < 1e-6
 
 
-@pytest.mark.parametrize("M,N,K", [(65536, 64, 576), (16384, 256, 1024), (4100, 32, 64), (300, 192, 768)])
+@pytest.mark.parametrize("M,N,K", [(65536, 64, 576), (16384, 256, 1024), (4100, 32, 64), (300, 192, 768), (1000, 24, 72), (333, 40, 136), (65536, 64, 576)])
 def test_gemm_tn_split_k(ops, M, N, K):
-    """weight-gradient product dW = dY^T X through transpose + split-K GEMM + split reduction."""
+    """weight-gradient product dW = dY^T X on the row-major activations (transposing LDS reads) + split reduction;
+    ragged M / N / K included."""
     dy = rnd(M, N, seed=1).to(torch.bfloat16)
     x = rnd(M, K, seed=2).to(torch.bfloat16)
     got = ops.gemm_tn(dy, x)
