@@ -191,10 +191,15 @@ int mfnet_scale_shift(const float* x, float* y, const float* mm, float unused, i
 
 /* per-(group, channel) sums over the P rows of each of G groups: sum [G,C] += sum_p x, sumsq += sum_p x*x
  * (sumsq may be null). BatchNorm statistics (G = 1), F.adaptive_avg_pool2d of SqueezeAndExcitation (:262)
- * and of FeatureRefinementHead.ca (:333). coldot: out [G,C] += sum_p a*b (gate gradients). Zero outputs first. */
-int mfnet_colsum(const void* x, int x_dtype, float* sum, float* sumsq, int64_t G, int64_t P, int64_t C, hipStream_t stream);
+ * and of FeatureRefinementHead.ca (:333). coldot: out [G,C] += sum_p a*b (gate gradients). Zero outputs first.
+ * The reductions are deterministic (no float atomics): `workspace` holds the workgroups' partial slabs
+ * (mfnet_colreduce_workspace_floats(G, P, C) floats, contents irrelevant) and `tickets` G unsigned ints that must
+ * be ZERO on entry and are zero again on completion (so one zeroed buffer serves every later call on the stream). */
+int64_t mfnet_colreduce_workspace_floats(int64_t G, int64_t P, int64_t C);
+int mfnet_colsum(const void* x, int x_dtype, float* sum, float* sumsq, int64_t G, int64_t P, int64_t C,
+                 float* workspace, unsigned int* tickets, hipStream_t stream);
 int mfnet_coldot(const void* a, int a_dtype, const void* b, int b_dtype, float* out, int64_t G, int64_t P, int64_t C,
-                 hipStream_t stream);
+                 float* workspace, unsigned int* tickets, hipStream_t stream);
 
 /* nn.BatchNorm2d (:27-73,126-129,508). finalize: training != 0: mean / rstd from the batch sums (biased
  * variance), running_mean / running_var updated with `momentum` (unbiased variance), num_batches_tracked += 1;
@@ -211,7 +216,8 @@ int mfnet_bn_apply(const void* x, int x_dtype, const float* mean, const float* r
                    int64_t rows, int64_t C, hipStream_t stream);
 int mfnet_bn_bwd_reduce(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd,
                         const float* gamma, const float* beta, int act, const float* chan_scale, int64_t rows_per_image,
-                        float* dsum, float* dxh, int64_t rows, int64_t C, hipStream_t stream);
+                        float* dsum, float* dxh, int64_t rows, int64_t C, float* workspace, unsigned int* tickets,
+                        hipStream_t stream);   /* workspace / tickets as for mfnet_colsum with G = 1 */
 int mfnet_bn_bwd_apply(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd,
                        const float* gamma, const float* beta, int act, const float* chan_scale, int64_t rows_per_image,
                        const float* dsum, const float* dxh, int training, void* dx, int dx_dtype, int64_t rows, int64_t C,

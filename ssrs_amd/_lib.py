@@ -61,11 +61,11 @@ _SIGS = {
     "mfnet_gather_segments": [P, I, I, I, P],
     "mfnet_gemm_tn_bf16": [P, I64, P, I64, I64, I64, I64, P, I64, I, P],
     # ---- FPN / SE-fusion / UNetFormer decoder (csrc/decoder.hip)
-    "mfnet_colsum": [P, I, P, P, I64, I64, I64, P],
-    "mfnet_coldot": [P, I, P, I, P, I64, I64, I64, P],
+    "mfnet_colsum": [P, I, P, P, I64, I64, I64, P, P, P],
+    "mfnet_coldot": [P, I, P, I, P, I64, I64, I64, P, P, P],
     "mfnet_bn_finalize": [P, P, P, P, P, P, P, I64, I64, F, F, I, P],
     "mfnet_bn_apply": [P, I, P, P, P, P, I, P, I64, P, I, P, I, I64, I64, P],
-    "mfnet_bn_bwd_reduce": [P, I, P, I, P, P, P, P, I, P, I64, P, P, I64, I64, P],
+    "mfnet_bn_bwd_reduce": [P, I, P, I, P, P, P, P, I, P, I64, P, P, I64, I64, P, P, P],
     "mfnet_bn_bwd_apply": [P, I, P, I, P, P, P, P, I, P, I64, P, P, I, P, I, I64, I64, P],
     "mfnet_act": [P, I, P, I, I, I64, P],
     "mfnet_act_bwd": [P, I, P, I, P, I, I, I64, P],
@@ -113,6 +113,8 @@ def lib():
         L.mfnet_version.argtypes = []
         L.mfnet_skinny_tn_workspace_floats.restype = c_int64
         L.mfnet_skinny_tn_workspace_floats.argtypes = [c_int64, c_int64, c_int, c_int]
+        L.mfnet_colreduce_workspace_floats.restype = c_int64
+        L.mfnet_colreduce_workspace_floats.argtypes = [c_int64, c_int64, c_int64]
         L.mfnet_gemm_tn_splits.restype = c_int64
         L.mfnet_gemm_tn_splits.argtypes = [c_int64, c_int64, c_int64]
         for name, sig in _SIGS.items():
@@ -126,7 +128,7 @@ def lib():
 
 
 def exported_symbols():
-    return ["mfnet_version", "mfnet_last_error", "mfnet_skinny_tn_workspace_floats", "mfnet_gemm_tn_splits"] + list(_SIGS)
+    return ["mfnet_version", "mfnet_last_error", "mfnet_skinny_tn_workspace_floats", "mfnet_gemm_tn_splits", "mfnet_colreduce_workspace_floats"] + list(_SIGS)
 
 
 def call(name: str, *args):

@@ -66,6 +66,7 @@ struct ColRedParams {
   int64_t P; int C; int64_t rpb; int mode;
   const float* mean; const float* rstd; const float* gamma; const float* beta; int act;
   const float* chan_scale; int64_t rows_per_image;       // optional [B, C] multiplier (Dropout2d mask)
+  float* partial; unsigned int* counter;                 // workspace: [G][splits][2][C] floats, [G] zeroed tickets
 };
 __global__ __launch_bounds__(256) void colreduce_kernel(const ColRedParams p) {
   __shared__ float4 red0[256], red1[256];
@@ -105,45 +106,88 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const ColRedParams p) {
   }
   red0[threadIdx.x] = s0; red1[threadIdx.x] = s1;
   __syncthreads();
+  // Deterministic finish without float atomics: every workgroup stores its partial row sums, the one that
+  // draws the last ticket of its group adds all of them in a fixed order (agent-scope release / acquire
+  // hand-off: plain stores -> vmcnt(0) -> barrier -> release fence -> relaxed ticket; the last arriver
+  // acquires, then reads the slabs with plain loads). The forward pass - BatchNorm statistics, SE / FRH pools -
+  // is therefore bit-reproducible, and so are the ReLU6 / max-pool decisions the backward pass follows.
+  const int splits = gridDim.x;
+  float* slab = p.partial + ((int64_t)g * splits + blockIdx.x) * 2 * p.C;
   if (threadIdx.x < C4) {
     for (int k = 1; k < nrl; ++k) { s0 = f4add(s0, red0[k * C4 + cg]); s1 = f4add(s1, red1[k * C4 + cg]); }
-    float* o0 = p.out0 + g * p.C + 4 * cg;
-    atomicAdd(o0, s0.x); atomicAdd(o0 + 1, s0.y); atomicAdd(o0 + 2, s0.z); atomicAdd(o0 + 3, s0.w);
-    if (p.out1) {
-      float* o1 = p.out1 + g * p.C + 4 * cg;
-      atomicAdd(o1, s1.x); atomicAdd(o1 + 1, s1.y); atomicAdd(o1 + 2, s1.z); atomicAdd(o1 + 3, s1.w);
+    reinterpret_cast<float4*>(slab)[cg] = s0;
+    reinterpret_cast<float4*>(slab + p.C)[cg] = s1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  __shared__ int last_arriver;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int ticket = __hip_atomic_fetch_add(p.counter + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_arriver = ticket == (unsigned)splits - 1;
+    if (last_arriver) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(p.counter + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
     }
   }
+  __syncthreads();
+  if (!last_arriver) return;
+  const float* slabs = p.partial + (int64_t)g * splits * 2 * p.C;
+  for (int c = threadIdx.x; c < 2 * p.C; c += 256) {
+    if (c >= p.C && !p.out1) break;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int sidx = 0;
+    for (; sidx + 3 < splits; sidx += 4) {
+      a0 += slabs[(int64_t)sidx * 2 * p.C + c]; a1 += slabs[(int64_t)(sidx + 1) * 2 * p.C + c];
+      a2 += slabs[(int64_t)(sidx + 2) * 2 * p.C + c]; a3 += slabs[(int64_t)(sidx + 3) * 2 * p.C + c];
+    }
+    for (; sidx < splits; ++sidx) a0 += slabs[(int64_t)sidx * 2 * p.C + c];
+    const float tot = (a0 + a1) + (a2 + a3);
+    if (c < p.C) p.out0[g * p.C + c] += tot; else p.out1[g * p.C + c - p.C] += tot;
+  }
 }
-static int launch_colreduce(ColRedParams& p, int64_t G, hipStream_t stream, const char* who) {
+static int64_t colreduce_splits(int64_t G, int64_t P, int C, int64_t* rpb_out) {
+  int64_t splits = ceil_div64(512, G);
+  if (splits > 128) splits = 128;                    // the last arriver sums the slabs serially per column
+  int64_t rpb = ceil_div64(P, splits);
+  const int nrl = 256 / (C / 4);
+  if (rpb < 8 * nrl) rpb = 8 * nrl;
+  if (rpb_out) *rpb_out = rpb;
+  return ceil_div64(P, rpb);
+}
+// floats of workspace for one column reduction over G groups of P rows x C columns (partial slabs)
+extern "C" int64_t mfnet_colreduce_workspace_floats(int64_t G, int64_t P, int64_t C) {
+  if (G <= 0 || P <= 0 || C <= 0 || C % 4 || C > 1024 || 256 % (C / 4)) return 0;
+  return G * colreduce_splits(G, P, (int)C, nullptr) * 2 * C;
+}
+static int launch_colreduce(ColRedParams& p, int64_t G, float* workspace, unsigned int* counters, hipStream_t stream, const char* who) {
   MF_CHECK_ARG(p.C > 0 && p.C % 4 == 0 && p.C <= 1024 && 256 % (p.C / 4) == 0, "%s: C=%d must be a multiple of 4 dividing 1024", who, p.C);
   MF_CHECK_ARG(G > 0 && G < 65536 && p.P > 0, "%s: bad group geometry", who);
-  // at most 128 workgroups add into one output row: the float atomics of the finish serialise per address
-  // (512 per address cost more than streaming the 17 MB map)
-  int64_t splits = ceil_div64(512, G);
-  if (splits > 128) splits = 128;
-  int64_t rpb = ceil_div64(p.P, splits);
-  const int nrl = 256 / (p.C / 4);
-  if (rpb < 8 * nrl) rpb = 8 * nrl;
-  splits = ceil_div64(p.P, rpb);
-  p.rpb = rpb;
+  MF_CHECK_ARG(workspace && counters, "%s: needs a workspace of mfnet_colreduce_workspace_floats(G, P, C) floats and G zeroed tickets", who);
+  int64_t rpb;
+  const int64_t splits = colreduce_splits(G, p.P, p.C, &rpb);
+  p.rpb = rpb; p.partial = workspace; p.counter = counters;
   hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)splits, (unsigned)G), dim3(256), 0, stream, p);
   MF_LAUNCH_CHECK(who);
   return MFNET_OK;
 }
 // x [G*P, C] -> sum [G, C] (+= ) and optionally sumsq [G, C]
-extern "C" int mfnet_colsum(const void* x, int x_dtype, float* sum, float* sumsq, int64_t G, int64_t P, int64_t C, hipStream_t stream) {
+extern "C" int mfnet_colsum(const void* x, int x_dtype, float* sum, float* sumsq, int64_t G, int64_t P, int64_t C,
+                            float* workspace, unsigned int* tickets, hipStream_t stream) {
   MF_CHECK_ARG(x && sum, "colsum: null pointer");
   ColRedParams p = {};
   p.a = x; p.a_dt = x_dtype; p.out0 = sum; p.out1 = sumsq; p.P = P; p.C = (int)C; p.mode = 0;
-  return launch_colreduce(p, G, stream, "colsum");
+  return launch_colreduce(p, G, workspace, tickets, stream, "colsum");
 }
 // out [G, C] += sum_p a[g,p,c] * b[g,p,c]
-extern "C" int mfnet_coldot(const void* a, int a_dtype, const void* b, int b_dtype, float* out, int64_t G, int64_t P, int64_t C, hipStream_t stream) {
+extern "C" int mfnet_coldot(const void* a, int a_dtype, const void* b, int b_dtype, float* out, int64_t G, int64_t P, int64_t C,
+                            float* workspace, unsigned int* tickets, hipStream_t stream) {
   MF_CHECK_ARG(a && b && out, "coldot: null pointer");
   ColRedParams p = {};
   p.a = a; p.a_dt = a_dtype; p.b = b; p.b_dt = b_dtype; p.out0 = out; p.out1 = nullptr; p.P = P; p.C = (int)C; p.mode = 1;
-  return launch_colreduce(p, G, stream, "coldot");
+  return launch_colreduce(p, G, workspace, tickets, stream, "coldot");
 }
 
 // =============================================================================== BatchNorm2d
@@ -210,12 +254,13 @@ extern "C" int mfnet_bn_apply(const void* x, int x_dtype, const float* mean, con
 // sums for the backward: dsum[c] += sum dy', dxh[c] += sum dy'*xhat  (= dbeta, dgamma)
 extern "C" int mfnet_bn_bwd_reduce(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd,
                                    const float* gamma, const float* beta, int act, const float* chan_scale, int64_t rows_per_image,
-                                   float* dsum, float* dxh, int64_t rows, int64_t C, hipStream_t stream) {
+                                   float* dsum, float* dxh, int64_t rows, int64_t C, float* workspace, unsigned int* tickets,
+                                   hipStream_t stream) {
   MF_CHECK_ARG(dy && x && mean && rstd && gamma && beta && dsum && dxh && act >= 0 && act <= 2, "bn_bwd_reduce: bad args");
   ColRedParams p = {};
   p.a = dy; p.a_dt = dy_dtype; p.b = x; p.b_dt = x_dtype; p.out0 = dsum; p.out1 = dxh; p.P = rows; p.C = (int)C; p.mode = 2;
   p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.act = act; p.chan_scale = chan_scale; p.rows_per_image = rows_per_image;
-  return launch_colreduce(p, 1, stream, "bn_bwd_reduce");
+  return launch_colreduce(p, 1, workspace, tickets, stream, "bn_bwd_reduce");
 }
 // dx = gamma*rstd*(dy' - [training](dsum/n + xhat*dxh/n))
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restrict__ dy, int dy_dt, const void* __restrict__ x, int x_dt,

@@ -404,13 +404,29 @@ def _dt(t):
     return _DT[t.dtype]
 
 
+_TICKETS = {}
+
+
+def _colreduce_ws(G, P, C, device):
+    """(partial-slab workspace, zeroed tickets) of a deterministic column reduction. The tickets are one
+    persistent zero buffer per device: every reduction leaves them zero again, and calls on one device are
+    stream-ordered."""
+    n = int(_lib.lib().mfnet_colreduce_workspace_floats(G, P, C))
+    t = _TICKETS.get(device)
+    if t is None or t.numel() < G:
+        t = _TICKETS[device] = torch.zeros(max(1024, G), dtype=torch.int32, device=device)
+    return torch.empty(max(n, 1), dtype=torch.float32, device=device), t
+
+
 def colsum(x, G, P, want_sq=False):
     """x [G*P, C] -> (sum [G,C], sumsq [G,C] | None), fp32."""
     _chk(x)
     C = x.shape[-1]
     assert x.is_contiguous() and x.numel() == G * P * C
     s = zeros((2 if want_sq else 1, G, C), x.device)
-    call("mfnet_colsum", x.data_ptr(), _dt(x), s[0].data_ptr(), s[1].data_ptr() if want_sq else None, G, P, C, _stream(x))
+    ws, tk = _colreduce_ws(G, P, C, x.device)
+    call("mfnet_colsum", x.data_ptr(), _dt(x), s[0].data_ptr(), s[1].data_ptr() if want_sq else None, G, P, C,
+         ws.data_ptr(), tk.data_ptr(), _stream(x))
     return s[0], (s[1] if want_sq else None)
 
 
@@ -419,7 +435,8 @@ def coldot(a, b, G, P):
     C = a.shape[-1]
     assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel() == G * P * C
     out = zeros((G, C), a.device)
-    call("mfnet_coldot", a.data_ptr(), _dt(a), b.data_ptr(), _dt(b), out.data_ptr(), G, P, C, _stream(a))
+    ws, tk = _colreduce_ws(G, P, C, a.device)
+    call("mfnet_coldot", a.data_ptr(), _dt(a), b.data_ptr(), _dt(b), out.data_ptr(), G, P, C, ws.data_ptr(), tk.data_ptr(), _stream(a))
     return out
 
 
@@ -450,8 +467,10 @@ def bn_backward(dy, x, mean, rstd, gamma, beta, training, act=ACT_NONE, chan_sca
     rows, C = x.shape
     assert dy.is_contiguous() and x.is_contiguous() and dy.shape == x.shape
     sums = zeros((2, C), x.device)
+    ws, tk = _colreduce_ws(1, rows, C, x.device)
     call("mfnet_bn_bwd_reduce", dy.data_ptr(), _dt(dy), x.data_ptr(), _dt(x), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
-         beta.data_ptr(), act, _p(chan_scale), rows_per_image, sums[0].data_ptr(), sums[1].data_ptr(), rows, C, _stream(x))
+         beta.data_ptr(), act, _p(chan_scale), rows_per_image, sums[0].data_ptr(), sums[1].data_ptr(), rows, C,
+         ws.data_ptr(), tk.data_ptr(), _stream(x))
     dx = torch.empty((rows, C), dtype=dx_dtype, device=x.device)
     call("mfnet_bn_bwd_apply", dy.data_ptr(), _dt(dy), x.data_ptr(), _dt(x), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
          beta.data_ptr(), act, _p(chan_scale), rows_per_image, sums[0].data_ptr(), sums[1].data_ptr(), 1 if training else 0,

@@ -226,6 +226,21 @@ def test_engine_gradients_equal_plain_autograd_and_bank_is_never_stale():
     assert (after - fresh).abs().max().item() <= 3e-2 * fresh.abs().max().item()
 
 
+def test_forward_is_bit_reproducible():
+    """eval AND train-mode forward passes give bit-identical logits run after run: no float atomic is left on
+    the forward path (BatchNorm statistics and the SE / FRH pools are fixed-order reductions)."""
+    m = _tiny()
+    m.load_state_dict(detfill.fill_state_dict(m.state_dict(), "repro/"))
+    m = m.cuda()
+    m.decoder.segmentation_head[1].p = 0.0
+    rgb, dsm, _ = [t.cuda() for t in detfill.tiles("repro", 2, 256, 6)]
+    for mode in (False, True):
+        m.train(mode)
+        with torch.no_grad():
+            outs = [m(rgb, dsm) for _ in range(4)]
+        assert all(torch.equal(outs[0], o) for o in outs[1:]), mode
+
+
 def test_confusion_and_metrics():
     from ssrs_amd import ops
     from ssrs_amd.inference import metrics_from_confusion

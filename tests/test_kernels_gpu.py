@@ -337,3 +337,20 @@ def test_gather_segments(ops):
     db = torch.zeros(17, 33, dtype=torch.bfloat16, device="cuda")
     ops.gather([(db, mats[3].t())])
     assert torch.equal(db, mats[3].t().to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------------------ column reductions
+@pytest.mark.parametrize("G,P,C,dt", [(1, 65536, 64, torch.float32), (1, 16384, 256, torch.bfloat16), (16, 4096, 64, torch.float32),
+                                      (3, 777, 256, torch.float32), (1, 100, 1024, torch.float32), (2, 9, 8, torch.bfloat16)])
+def test_colsum_coldot_deterministic(ops, G, P, C, dt):
+    """BatchNorm statistics / SE pools: values against float64, and bit-identical results run after run (the
+    finish is a fixed-order sum of per-workgroup slabs, not float atomics)."""
+    x = rnd(G * P, C, seed=1).to(dt)
+    y = rnd(G * P, C, seed=2).to(dt)
+    s, sq = ops.colsum(x, G, P, want_sq=True)
+    d = ops.coldot(x, y, G, P)
+    xd, yd = x.double().view(G, P, C), y.double().view(G, P, C)
+    assert rel_err(s, xd.sum(1)) < 1e-5 and rel_err(sq, (xd * xd).sum(1)) < 1e-5 and rel_err(d, (xd * yd).sum(1)) < 1e-5
+    for _ in range(5):
+        s2, sq2 = ops.colsum(x, G, P, want_sq=True)
+        assert torch.equal(s, s2) and torch.equal(sq, sq2) and torch.equal(d, ops.coldot(x, y, G, P))
