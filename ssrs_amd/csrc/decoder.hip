@@ -83,47 +83,67 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const ColRedParams p) {
     ga = reinterpret_cast<const float4*>(p.gamma)[cg]; be = reinterpret_cast<const float4*>(p.beta)[cg];
   }
   if (rl < nrl) {
-#pragma unroll 4
-    for (int64_t r = r0 + rl; r < r1; r += nrl) {
-      const int64_t row = g * p.P + r;
-      const float4 a = ld4(p.a, p.a_dt, row * C4 + cg);
-      if (p.mode == 0) {
-        s0 = f4add(s0, a); s1 = f4fma(a, a, s1);
-      } else if (p.mode == 1) {
-        s0 = f4fma(a, ld4(p.b, p.b_dt, row * C4 + cg), s0);
-      } else {
-        const float4 x = ld4(p.b, p.b_dt, row * C4 + cg);
-        const float4 xh = make_float4((x.x - mu.x) * rs.x, (x.y - mu.y) * rs.y, (x.z - mu.z) * rs.z, (x.w - mu.w) * rs.w);
-        float4 d = a;
-        if (p.chan_scale) d = f4mul(d, reinterpret_cast<const float4*>(p.chan_scale)[(row / p.rows_per_image) * C4 + cg]);
-        if (p.act != ACT_NONE) {
-          d.x *= act_grad_f(fmaf(ga.x, xh.x, be.x), p.act); d.y *= act_grad_f(fmaf(ga.y, xh.y, be.y), p.act);
-          d.z *= act_grad_f(fmaf(ga.z, xh.z, be.z), p.act); d.w *= act_grad_f(fmaf(ga.w, xh.w, be.w), p.act);
+    // eight rows per thread are requested before any is consumed: the kernel streams the map once and is bound
+    // by the bytes in flight (rows past the end re-read the last row and are discarded)
+    for (int64_t rb = r0 + rl; rb < r1; rb += 8 * nrl) {
+      float4 av[8], bv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        int64_t r = rb + (int64_t)k * nrl;
+        r = r < r1 ? r : r1 - 1;
+        const int64_t row = g * p.P + r;
+        av[k] = ld4(p.a, p.a_dt, row * C4 + cg);
+        if (p.mode != 0) bv[k] = ld4(p.b, p.b_dt, row * C4 + cg);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int64_t r = rb + (int64_t)k * nrl;
+        if (r >= r1) break;
+        const float4 a = av[k];
+        if (p.mode == 0) {
+          s0 = f4add(s0, a); s1 = f4fma(a, a, s1);
+        } else if (p.mode == 1) {
+          s0 = f4fma(a, bv[k], s0);
+        } else {
+          const float4 x = bv[k];
+          const float4 xh = make_float4((x.x - mu.x) * rs.x, (x.y - mu.y) * rs.y, (x.z - mu.z) * rs.z, (x.w - mu.w) * rs.w);
+          float4 d = a;
+          if (p.chan_scale) d = f4mul(d, reinterpret_cast<const float4*>(p.chan_scale)[((g * p.P + r) / p.rows_per_image) * C4 + cg]);
+          if (p.act != ACT_NONE) {
+            d.x *= act_grad_f(fmaf(ga.x, xh.x, be.x), p.act); d.y *= act_grad_f(fmaf(ga.y, xh.y, be.y), p.act);
+            d.z *= act_grad_f(fmaf(ga.z, xh.z, be.z), p.act); d.w *= act_grad_f(fmaf(ga.w, xh.w, be.w), p.act);
+          }
+          s0 = f4add(s0, d); s1 = f4fma(d, xh, s1);
         }
-        s0 = f4add(s0, d); s1 = f4fma(d, xh, s1);
       }
     }
   }
   red0[threadIdx.x] = s0; red1[threadIdx.x] = s1;
   __syncthreads();
   // Deterministic finish without float atomics: every workgroup stores its partial row sums, the one that
-  // draws the last ticket of its group adds all of them in a fixed order (agent-scope release / acquire
-  // hand-off: plain stores -> vmcnt(0) -> barrier -> release fence -> relaxed ticket; the last arriver
-  // acquires, then reads the slabs with plain loads). The forward pass - BatchNorm statistics, SE / FRH pools -
+  // draws the last ticket of its group adds all of them in a fixed order (agent-scope hand-off:
+  // write-through slab stores -> vmcnt(0) -> barrier -> relaxed ticket; the last arriver acquires, then reads
+  // the slabs with plain loads). The forward pass - BatchNorm statistics, SE / FRH pools -
   // is therefore bit-reproducible, and so are the ReLU6 / max-pool decisions the backward pass follows.
   const int splits = gridDim.x;
   float* slab = p.partial + ((int64_t)g * splits + blockIdx.x) * 2 * p.C;
   if (threadIdx.x < C4) {
     for (int k = 1; k < nrl; ++k) { s0 = f4add(s0, red0[k * C4 + cg]); s1 = f4add(s1, red1[k * C4 + cg]); }
-    reinterpret_cast<float4*>(slab)[cg] = s0;
-    reinterpret_cast<float4*>(slab + p.C)[cg] = s1;
+    // write-through (sc1) 8-byte stores: the slab needs no release fence, which would write back every dirty
+    // line of this XCD's L2 - typically the map the previous kernel just produced
+    typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+    union { float2 f; unsigned long long u; } w;
+    gu64_t* d0 = (gu64_t*)(slab + 4 * cg);
+    gu64_t* d1 = (gu64_t*)(slab + p.C + 4 * cg);
+    w.f = make_float2(s0.x, s0.y); __hip_atomic_store(d0, w.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    w.f = make_float2(s0.z, s0.w); __hip_atomic_store(d0 + 1, w.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    w.f = make_float2(s1.x, s1.y); __hip_atomic_store(d1, w.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    w.f = make_float2(s1.z, s1.w); __hip_atomic_store(d1 + 1, w.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   __shared__ int last_arriver;
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned int ticket = __hip_atomic_fetch_add(p.counter + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last_arriver = ticket == (unsigned)splits - 1;
     if (last_arriver) {
@@ -134,23 +154,39 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const ColRedParams p) {
   }
   __syncthreads();
   if (!last_arriver) return;
+  // The slabs were written through to memory by other XCDs: every load here is a long-latency miss. Threads
+  // read float4s, 16 in flight each, and share a column group between `parts` threads (fixed partition and
+  // summation order: still deterministic), so the tail is one or a few memory round trips.
   const float* slabs = p.partial + (int64_t)g * splits * 2 * p.C;
-  for (int c = threadIdx.x; c < 2 * p.C; c += 256) {
-    if (c >= p.C && !p.out1) break;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int sidx = 0;
-    for (; sidx + 3 < splits; sidx += 4) {
-      a0 += slabs[(int64_t)sidx * 2 * p.C + c]; a1 += slabs[(int64_t)(sidx + 1) * 2 * p.C + c];
-      a2 += slabs[(int64_t)(sidx + 2) * 2 * p.C + c]; a3 += slabs[(int64_t)(sidx + 3) * 2 * p.C + c];
+  const int ncg = (p.out1 ? 2 * p.C : p.C) >> 2;     // float4 column groups to finish
+  const int cpp = ncg < 256 ? ncg : 256;             // column groups per pass
+  const int parts = 256 / cpp;
+  for (int c0 = 0; c0 < ncg; c0 += cpp) {
+    const int cl = threadIdx.x % cpp, part = threadIdx.x / cpp, c4 = c0 + cl;
+    float4 tot = F4ZERO;
+    for (int sb = part; sb < splits; sb += 16 * parts) {
+      float4 v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int si = sb + k * parts;
+        v[k] = si < splits ? reinterpret_cast<const float4*>(slabs + (int64_t)si * 2 * p.C)[c4] : F4ZERO;
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) tot = f4add(tot, v[k]);
     }
-    for (; sidx < splits; ++sidx) a0 += slabs[(int64_t)sidx * 2 * p.C + c];
-    const float tot = (a0 + a1) + (a2 + a3);
-    if (c < p.C) p.out0[g * p.C + c] += tot; else p.out1[g * p.C + c - p.C] += tot;
+    __syncthreads();
+    red0[part * cpp + cl] = tot;
+    __syncthreads();
+    if (part == 0) {
+      for (int k = 1; k < parts; ++k) tot = f4add(tot, red0[k * cpp + cl]);
+      float* o = 4 * c4 < p.C ? p.out0 + g * p.C + 4 * c4 : p.out1 + g * p.C + 4 * c4 - p.C;
+      o[0] += tot.x; o[1] += tot.y; o[2] += tot.z; o[3] += tot.w;
+    }
   }
 }
 static int64_t colreduce_splits(int64_t G, int64_t P, int C, int64_t* rpb_out) {
   int64_t splits = ceil_div64(512, G);
-  if (splits > 128) splits = 128;                    // the last arriver sums the slabs serially per column
+  if (splits > 128) splits = 128;                    // the last arriver reads every slab (long-latency loads)
   int64_t rpb = ceil_div64(P, splits);
   const int nrl = 256 / (C / 4);
   if (rpb < 8 * nrl) rpb = 8 * nrl;
