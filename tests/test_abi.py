@@ -37,6 +37,18 @@ def test_argument_errors_do_not_launch():
     assert rc == -1 and b"multiple of 8" in L.mfnet_last_error()
     with pytest.raises(_lib.MfnetError):
         _lib.call("mfnet_attn_fwd", 1, 1, 1, 1, 1, 1, 16, 16, 12, 32, 14, 27, 27, 64, 0.125, None)   # hd != 64
+    # weight-gradient GEMM: N / K must be multiples of 8; split count helper is pure host code
+    rc = L.mfnet_gemm_tn_bf16(16, 64, 16, 64, 128, 60, 64, 16, 64, 1, None)
+    assert rc == -1 and b"multiples of 8" in L.mfnet_last_error()
+    assert L.mfnet_gemm_tn_splits(65536, 64, 576) >= 2 and L.mfnet_gemm_tn_splits(100, 64, 64) == 1
+    # gather: a segment with a null pointer / an accumulate into bf16 is refused
+    desc = (ctypes.c_int64 * 14)(0, 16, 1, 1, 1, 4, 0, 0, 0, 1, 0, 0, 0, 1)
+    assert L.mfnet_gather_segments(ctypes.cast(desc, ctypes.c_void_p), 1, 0, 0, None) == -1 and b"null" in L.mfnet_last_error()
+    assert L.mfnet_gather_segments(ctypes.cast(desc, ctypes.c_void_p), 1, 1, 1, None) == -1
+    # deterministic column reductions need their workspace
+    assert L.mfnet_colreduce_workspace_floats(1, 65536, 64) == 128 * 2 * 64
+    rc = L.mfnet_colsum(16, 0, 16, None, 1, 1024, 64, None, None, None)
+    assert rc == -1 and b"workspace" in L.mfnet_last_error()
 
 
 def test_product_rejects_cpu_tensors():
