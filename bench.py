@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--mod", default="sam_lora")
     ap.add_argument("--encoder", default="vit_b")
     ap.add_argument("--classes", type=int, default=6)
+    ap.add_argument("--tile", type=int, default=256, help="tile edge in pixels (BASELINE configs[1]: 256; config 5: 1024)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a HIP graph")
@@ -117,7 +118,7 @@ def main():
     model = build_model(a.mod, a.encoder, a.classes, dev)
     eng = TrainEngine(model, lr=0.01, momentum=0.9, weight_decay=5e-4, class_weight=torch.ones(a.classes, device=dev),
                       use_graph=not a.eager)
-    rgb, dsm, tgt = detfill.tiles(f"bench/rank{rank}", a.batch, 256, a.classes)
+    rgb, dsm, tgt = detfill.tiles(f"bench/rank{rank}", a.batch, a.tile, a.classes)
     rgb, dsm, tgt = rgb.to(dev), dsm.to(dev), tgt.to(dev)
 
     def sync():
@@ -165,7 +166,7 @@ def main():
         traffic = None
         import glob
         pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "*gemm_pmc.json")))
-        if pmc and a.mod == "sam_lora" and a.batch == 16 and a.encoder == "vit_b":
+        if pmc and a.mod == "sam_lora" and a.batch == 16 and a.encoder == "vit_b" and a.tile == 256:
             with open(pmc[-1]) as f:
                 traffic = round(json.load(f)["traffic_bytes_per_launch"])
         roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(achieved, 2),
@@ -185,15 +186,17 @@ def main():
 
     if rank == 0:
         tiles = world * a.batch * a.steps
-        out = {"metric": "train tiles/sec (256x256 RGB+DSM, ViT-B MMLoRA)" if a.mod == "sam_lora" else f"train tiles/sec (256x256 RGB+DSM, {a.encoder} {a.mod})",
+        base_cfg = a.mod == "sam_lora" and a.encoder == "vit_b" and a.tile == 256
+        out = {"metric": "train tiles/sec (256x256 RGB+DSM, ViT-B MMLoRA)" if base_cfg else f"train tiles/sec ({a.tile}x{a.tile} RGB+DSM, {a.encoder} {a.mod})",
                "value": round(tiles / dt, 2), "unit": "tiles/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": f"{a.encoder} {a.mod} fine-tune step (fwd+CE+bwd+SGD), {a.batch} tiles of 256x256 RGB+DSM per GPU, "
-                                      f"{a.classes} classes, bf16 MFMA / fp32 accumulate+master (BASELINE configs[1])",
+               "config": {"workload": f"{a.encoder} {a.mod} fine-tune step (fwd+CE+bwd+SGD), {a.batch} tiles of {a.tile}x{a.tile} RGB+DSM per GPU, "
+                                      f"{a.classes} classes, bf16 MFMA / fp32 accumulate+master" + (" (BASELINE configs[1])" if base_cfg and a.batch == 16 else ""),
                           "tiles_per_gpu": a.batch, "global_batch": world * a.batch, "parallelism": f"dp{world}"},
                "loss": round(metrics["loss"], 5),
-               "algorithmic_train_tflops": round(world * a.batch * TRAIN_GF_PER_TILE.get(a.mod, 191.0) * 1e9 / (dt / a.steps) / 1e12, 2)}
+               "algorithmic_train_tflops": (round(world * a.batch * TRAIN_GF_PER_TILE.get(a.mod, 191.0) * 1e9 / (dt / a.steps) / 1e12, 2)
+                                            if a.encoder == "vit_b" and a.tile == 256 else None)}
         if roofline is not None:
             out["roofline"] = roofline
         if world == 1 and not a.no_cpu:

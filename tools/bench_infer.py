@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Sliding-window inference throughput on a synthetic raster resident in HBM.
+
+    python tools/bench_infer.py [--size 8192] [--batch 32] [--encoder vit_b] [--mod sam_lora]
+
+(i)  inference.py grid: 256-px windows, overlap 0.25 -> stride 192, per-tile DSM min-max, softmax[1] blend
+     (RasterInference; reference inference.py:498-568,687-744);
+(ii) evaluator grid: stride 64 with clamped tail positions, whole-raster DSM min-max, pred += logits, arg-max
+     (SlidingWindowPredictor; reference evaluator.py:113-176, utils2.py:134-165).
+Prints one JSON line per grid: window visits per second and seconds per raster."""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=8192)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--encoder", default="vit_b")
+    ap.add_argument("--mod", default="sam_lora")
+    ap.add_argument("--skip-evaluator", action="store_true")
+    a = ap.parse_args()
+    from ssrs_amd import detfill
+    from ssrs_amd.inference import RasterInference, SlidingWindowPredictor, get_sliding_windows, sliding_window
+    from ssrs_amd.unetformer_mmsam import UNetFormer
+    dev = torch.device("cuda")
+    out = []
+    for ncls, kind in ((2, "inference.py grid"), (6, "evaluator grid")):
+        if kind.startswith("evaluator") and a.skip_evaluator:
+            continue
+        args = argparse.Namespace(mod=a.mod, mid_dim=None, image_size=1024, multimask_output=1)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = UNetFormer(num_classes=ncls, encoder=a.encoder, args=args)
+        m.load_state_dict(detfill.fill_state_dict(m.state_dict(), "infer/"))
+        m = m.to(dev).eval()
+        g = torch.Generator(device="cpu").manual_seed(0)
+        rgb = torch.randint(0, 256, (3, a.size, a.size), dtype=torch.uint8, generator=g).to(dev)
+        dsm = (torch.rand(a.size, a.size, generator=g) * 50.0).to(dev)
+        fwd = lambda x, y: m(x, y)                           # noqa: E731
+        if kind.startswith("inference"):
+            eng = RasterInference(fwd, batch_size=a.batch)
+            n = len(get_sliding_windows(a.size, a.size, (256, 256), eng.overlap))
+            run = lambda: eng.predict(rgb, dsm)              # noqa: E731
+            warm = RasterInference(fwd, batch_size=a.batch)
+            small = (rgb[:, :1024, :1024].contiguous(), dsm[:1024, :1024].contiguous())
+            warm.predict(*small)
+        else:
+            eng = SlidingWindowPredictor(fwd, ncls, batch_size=a.batch)
+            img = rgb.float() / 255.0
+            n = sum(1 for _ in sliding_window((a.size, a.size), 64, (256, 256)))
+            run = lambda: eng.predict(img, dsm, 64)          # noqa: E731
+            eng.predict(img[:, :1024, :1024].contiguous(), dsm[:1024, :1024].contiguous(), 64)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        line = {"metric": "sliding-window inference window visits/sec", "grid": kind, "raster": f"{a.size}x{a.size}", "windows": n,
+                "value": round(n / dt, 1), "unit": "windows/s", "seconds_per_raster": round(dt, 3), "batch": a.batch,
+                "model": f"{a.encoder} {a.mod}, {ncls} classes", "dtype": "bf16", "data": "synthetic"}
+        print(json.dumps(line), flush=True)
+        out.append(line)
+        del m, eng
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
