@@ -302,13 +302,22 @@ int mfnet_add3(const void* a, int a_dtype, const void* b, int b_dtype, const voi
  * normalize_rgb_u8: out[c] = (in[c]*scale - mean3[c]) / std3[c] on a [3,H,W] uint8 raster (:464-484; mean3 /
  * std3 are HOST arrays). extract_tiles: coords[t] = (row, col, valid_h, valid_w) int32; tiles shorter than the
  * h x w window are filled with numpy 'reflect' padding (:726-737). tile_minmax_norm: per-tile DSM min-max in
- * place, 0 when max == min (:547-555). tile_prob_accumulate: sum[row+y, col+x] += softmax(logits[t])[cls],
+ * place; a flat tile (max == min) becomes 0 (:547-555) or, with keep_flat, stays as it is (multiscale_dataset.py:206). tile_prob_accumulate: sum[row+y, col+x] += softmax(logits[t])[cls],
  * cnt += 1 over each tile's valid extent (:562-566). blend_finish: prob = sum/cnt, mask = prob > threshold (:582). */
 int mfnet_normalize_rgb_u8(const unsigned char* in, float* out, int64_t H, int64_t W, float scale, const float* mean3,
                            const float* std3, hipStream_t stream);
 int mfnet_extract_tiles(const float* rgb, const float* dsm, const int* coords, float* rgb_out, float* dsm_out, int64_t n,
                         int64_t C, int64_t H, int64_t W, int64_t h, int64_t w, hipStream_t stream);
-int mfnet_tile_minmax_norm(float* tiles, int64_t n, int64_t per_tile, hipStream_t stream);
+int mfnet_tile_minmax_norm(float* tiles, int64_t n, int64_t per_tile, int keep_flat, hipStream_t stream);
+
+/* Training input pipeline on the device (multiscale_dataset.py:190-215 normalisation, :228-245 flips / rot90):
+ * per square S x S tile t, out = rot90^k(vflip?(hflip?(in))) for RGB (uint8 [n,3,S,S] -> fp32 (v/255 - mean)/std),
+ * DSM (fp32 [n,S,S], optional) and labels (int64 [n,S,S], optional); codes[t]: bit 0 horizontal flip, bit 1
+ * vertical flip, bits 2-3 = k (np.rot90, counter-clockwise). mean3 / std3 are HOST arrays. The reference's per-tile
+ * DSM min-max (:205-208) is mfnet_tile_minmax_norm on dsm_out. */
+int mfnet_prepare_tiles(const unsigned char* rgb, const float* dsm, const int64_t* labels, const int* codes,
+                        float* rgb_out, float* dsm_out, int64_t* labels_out, int64_t n, int64_t S,
+                        const float* mean3, const float* std3, hipStream_t stream);
 int mfnet_tile_prob_accumulate(float* sum, float* cnt, const float* logits, const int* coords, int64_t n, int64_t C, int64_t H,
                                int64_t W, int64_t h, int64_t w, int64_t cls, hipStream_t stream);
 int mfnet_blend_finish(const float* sum, const float* cnt, float* prob, unsigned char* mask, float threshold, int64_t n,

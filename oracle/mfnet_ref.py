@@ -504,3 +504,30 @@ def confusion_metrics(pred, gt, n_classes: int):
         kappa = (pa - pe) / (1 - pe)
         iou = np.diag(cm) / (cm.sum(1) + cm.sum(0) - np.diag(cm))
     return dict(cm=cm, OA=oa, F1=f1, kappa=kappa, mIoU=float(np.nanmean(iou[:5])))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# training input pipeline (multiscale_dataset.py:190-215, 228-245) - numpy, exactly the reference's call order
+def augment_patch(data, dsm, label, hflip, vflip, rot_k):
+    """data uint8 [3,S,S], dsm [S,S], label [S,S]: np.flip / np.rot90 in the reference's order (:228-245)."""
+    import numpy as np
+    if hflip:
+        data, dsm, label = np.flip(data, axis=2).copy(), np.flip(dsm, axis=1).copy(), np.flip(label, axis=1).copy()
+    if vflip:
+        data, dsm, label = np.flip(data, axis=1).copy(), np.flip(dsm, axis=0).copy(), np.flip(label, axis=0).copy()
+    if rot_k:
+        data = np.rot90(data, k=rot_k, axes=(1, 2)).copy()
+        dsm, label = np.rot90(dsm, k=rot_k, axes=(0, 1)).copy(), np.rot90(label, k=rot_k, axes=(0, 1)).copy()
+    return data, dsm, label
+
+
+def normalise_patch(data, dsm, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """(:199-208) RGB / 255 then per-channel (x - mean) / std; DSM min-max to [0,1] when max > min."""
+    import numpy as np
+    d = data.astype(np.float32) / 255.0
+    for c in range(3):
+        d[c] = (d[c] - mean[c]) / std[c]
+    z = dsm.astype(np.float32)
+    if z.max() > z.min():
+        z = (z - z.min()) / (z.max() - z.min())
+    return d.astype(np.float32), z.astype(np.float32)

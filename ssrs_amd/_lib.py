@@ -59,6 +59,7 @@ _SIGS = {
     "mfnet_transpose_bf16": [P, I64, P, I64, I64, I64, P],
     "mfnet_reduce_splits": [P, P, I64, I, F, I, P],
     "mfnet_gather_segments": [P, I, I, I, P],
+    "mfnet_prepare_tiles": [P, P, P, P, P, P, P, I64, I64, P, P, P],
     "mfnet_gemm_tn_bf16": [P, I64, P, I64, I64, I64, I64, P, I64, I, P],
     # ---- FPN / SE-fusion / UNetFormer decoder (csrc/decoder.hip)
     "mfnet_colsum": [P, I, P, P, I64, I64, I64, P, P, P],
@@ -92,7 +93,7 @@ _SIGS = {
     # ---- raster inference pre / post (csrc/infer.hip)
     "mfnet_normalize_rgb_u8": [P, P, I64, I64, F, P, P, P],
     "mfnet_extract_tiles": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, P],
-    "mfnet_tile_minmax_norm": [P, I64, I64, P],
+    "mfnet_tile_minmax_norm": [P, I64, I64, I, P],
     "mfnet_tile_prob_accumulate": [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, P],
     "mfnet_blend_finish": [P, P, P, P, F, I64, P],
     "mfnet_confusion": [P, P, P, I64, I64, P],

@@ -63,7 +63,7 @@ extern "C" int mfnet_extract_tiles(const float* rgb, const float* dsm, const int
 }
 
 // per-tile min-max normalisation in place: (x - min) / (max - min), 0 when max == min; one block per tile
-__global__ __launch_bounds__(256) void tile_minmax_norm_kernel(float* __restrict__ x, int64_t per) {
+__global__ __launch_bounds__(256) void tile_minmax_norm_kernel(float* __restrict__ x, int64_t per, int keep_flat) {
   __shared__ float lo_s[4], hi_s[4];
   float* p = x + (int64_t)blockIdx.x * per;
   float lo = FLT_MAX, hi = -FLT_MAX;
@@ -74,12 +74,13 @@ __global__ __launch_bounds__(256) void tile_minmax_norm_kernel(float* __restrict
   lo = fminf(fminf(lo_s[0], lo_s[1]), fminf(lo_s[2], lo_s[3]));
   hi = fmaxf(fmaxf(hi_s[0], hi_s[1]), fmaxf(hi_s[2], hi_s[3]));
   const float rng = hi - lo;
+  if (!(rng > 0.f) && keep_flat) return;       // multiscale_dataset.py:206 leaves a flat patch as it is
   for (int64_t i = threadIdx.x; i < per; i += 256) p[i] = rng > 0.f ? (p[i] - lo) / rng : 0.f;
 }
-extern "C" int mfnet_tile_minmax_norm(float* tiles, int64_t n, int64_t per_tile, hipStream_t stream) {
+extern "C" int mfnet_tile_minmax_norm(float* tiles, int64_t n, int64_t per_tile, int keep_flat, hipStream_t stream) {
   MF_CHECK_ARG(tiles && per_tile > 0 && n < (1ll << 31), "tile_minmax_norm: bad args");
   if (n <= 0) return MFNET_OK;
-  hipLaunchKernelGGL(tile_minmax_norm_kernel, dim3((unsigned)n), dim3(256), 0, stream, tiles, per_tile);
+  hipLaunchKernelGGL(tile_minmax_norm_kernel, dim3((unsigned)n), dim3(256), 0, stream, tiles, per_tile, keep_flat);
   MF_LAUNCH_CHECK("tile_minmax_norm");
   return MFNET_OK;
 }
@@ -152,5 +153,56 @@ extern "C" int mfnet_confusion(const unsigned char* pred, const int64_t* gt, int
   if (total == 0) return MFNET_OK;
   hipLaunchKernelGGL(confusion_kernel, dim3(grid_for(total, 1024)), dim3(256), 0, stream, pred, gt, (unsigned long long*)cm, (int)n_classes, total);
   MF_LAUNCH_CHECK("confusion");
+  return MFNET_OK;
+}
+
+// =====================================================================================================
+// Training input pipeline on the device (multiscale_dataset.py:190-215 normalisation, :228-245 geometric
+// augmentation): per tile, out = rot90^k(vflip?(hflip?(in))) applied to RGB, DSM and labels alike, RGB uint8 ->
+// (v/255 - mean)/std. code[t]: bit 0 horizontal flip (np.flip axis W), bit 1 vertical flip (axis H), bits 2-3 =
+// k of np.rot90(axes=(H, W)) (counter-clockwise). The per-tile DSM min-max that follows in the reference
+// (:205-208) is mfnet_tile_minmax_norm on dsm_out.
+struct PrepParams { float scale[3], shift[3]; };
+__global__ __launch_bounds__(256) void prepare_tiles_kernel(const unsigned char* __restrict__ rgb, const float* __restrict__ dsm,
+                                                            const int64_t* __restrict__ lab, const int* __restrict__ code,
+                                                            float* __restrict__ rgb_out, float* __restrict__ dsm_out,
+                                                            int64_t* __restrict__ lab_out, int64_t n, int S, PrepParams pp) {
+  const int64_t per = (int64_t)S * S, total = n * per;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / per;
+    const int r = (int)(i - t * per);
+    const int y = r / S, x = r - y * S;
+    const int c = code[t];
+    const int k = (c >> 2) & 3;
+    int sy, sx;                       // undo the rotation: np.rot90(m, 1)[i][j] = m[j][S-1-i]
+    if (k == 0) { sy = y; sx = x; }
+    else if (k == 1) { sy = x; sx = S - 1 - y; }
+    else if (k == 2) { sy = S - 1 - y; sx = S - 1 - x; }
+    else { sy = S - 1 - x; sx = y; }
+    if (c & 2) sy = S - 1 - sy;       // undo the vertical flip
+    if (c & 1) sx = S - 1 - sx;       // undo the horizontal flip
+    const int64_t src = (int64_t)sy * S + sx;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+      rgb_out[(t * 3 + ch) * per + r] = fmaf((float)rgb[(t * 3 + ch) * per + src], pp.scale[ch], pp.shift[ch]);
+    if (dsm) dsm_out[t * per + r] = dsm[t * per + src];
+    if (lab) lab_out[t * per + r] = lab[t * per + src];
+  }
+}
+extern "C" int mfnet_prepare_tiles(const unsigned char* rgb, const float* dsm, const int64_t* labels, const int* codes,
+                                   float* rgb_out, float* dsm_out, int64_t* labels_out, int64_t n, int64_t S,
+                                   const float* mean3, const float* std3, hipStream_t stream) {
+  MF_CHECK_ARG(rgb && codes && rgb_out && mean3 && std3 && S > 0 && S < 32768, "prepare_tiles: bad args");
+  MF_CHECK_ARG((!dsm || dsm_out) && (!labels || labels_out), "prepare_tiles: an input without its output");
+  if (n <= 0) return MFNET_OK;
+  PrepParams pp;
+  for (int c = 0; c < 3; ++c) {
+    MF_CHECK_ARG(std3[c] != 0.f, "prepare_tiles: std must be non-zero");
+    pp.scale[c] = 1.0f / (255.0f * std3[c]);
+    pp.shift[c] = -mean3[c] / std3[c];
+  }
+  hipLaunchKernelGGL(prepare_tiles_kernel, dim3(grid_for(n * S * S)), dim3(256), 0, stream, rgb, dsm, labels, codes, rgb_out, dsm_out,
+                     labels_out, n, (int)S, pp);
+  MF_LAUNCH_CHECK("prepare_tiles");
   return MFNET_OK;
 }

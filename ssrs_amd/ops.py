@@ -709,11 +709,29 @@ def extract_tiles(rgb, dsm, coords4, h, w):
     return ro, do
 
 
-def tile_minmax_norm(tiles):
+def tile_minmax_norm(tiles, keep_flat=False):
     _chk(tiles)
     assert tiles.is_contiguous() and tiles.dtype == torch.float32
-    call("mfnet_tile_minmax_norm", tiles.data_ptr(), tiles.shape[0], tiles[0].numel(), _stream(tiles))
+    call("mfnet_tile_minmax_norm", tiles.data_ptr(), tiles.shape[0], tiles[0].numel(), 1 if keep_flat else 0, _stream(tiles))
     return tiles
+
+
+def prepare_tiles(rgb_u8, dsm, labels, codes, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """rgb uint8 [n,3,S,S], dsm fp32 [n,S,S] | None, labels int64 [n,S,S] | None, codes int32 [n] (bit 0 hflip,
+    bit 1 vflip, bits 2-3 rot90 k) -> (rgb fp32 normalised, dsm, labels), all transformed alike."""
+    import ctypes
+    _chk(rgb_u8, dsm, labels, codes)
+    n, _, S, S2 = rgb_u8.shape
+    assert S == S2 and rgb_u8.dtype == torch.uint8 and rgb_u8.is_contiguous() and codes.dtype == torch.int32 and codes.numel() == n
+    assert dsm is None or (dsm.dtype == torch.float32 and dsm.is_contiguous() and tuple(dsm.shape) == (n, S, S))
+    assert labels is None or (labels.dtype == torch.int64 and labels.is_contiguous() and tuple(labels.shape) == (n, S, S))
+    ro = torch.empty((n, 3, S, S), dtype=torch.float32, device=rgb_u8.device)
+    do = torch.empty_like(dsm) if dsm is not None else None
+    lo = torch.empty_like(labels) if labels is not None else None
+    m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    call("mfnet_prepare_tiles", rgb_u8.data_ptr(), _p(dsm), _p(labels), codes.data_ptr(), ro.data_ptr(), _p(do), _p(lo), n, S,
+         ctypes.cast(m3, ctypes.c_void_p), ctypes.cast(s3, ctypes.c_void_p), _stream(rgb_u8))
+    return ro, do, lo
 
 
 def tile_prob_accumulate(psum, cnt, logits, coords4, cls):

@@ -252,3 +252,27 @@ def test_confusion_and_metrics():
     ref = R.confusion_metrics(p, gt, 6)
     assert np.array_equal(cm, ref["cm"])
     assert abs(metrics_from_confusion(cm)["mIoU"] - ref["mIoU"]) < 1e-12
+
+
+def test_device_input_pipeline_matches_numpy_reference_order():
+    """DeviceAugment (flip / rot90 / ImageNet normalisation / per-tile DSM min-max on the GPU) against the
+    numpy restatement of MultiScaleDataset.__getitem__ / _apply_augmentation, every one of the 16 codes."""
+    from oracle import mfnet_ref as R
+    from ssrs_amd.data import DeviceAugment, random_codes
+    S, n = 64, 16
+    g = np.random.default_rng(0)
+    rgb = g.integers(0, 256, (n, 3, S, S), dtype=np.uint8)
+    dsm = (g.random((n, S, S), dtype=np.float32) * 40 + 100).astype(np.float32)
+    dsm[5] = 7.0                                                     # flat tile: max == min stays as is (:206)
+    lab = g.integers(0, 6, (n, S, S), dtype=np.int64)
+    codes = torch.arange(n, dtype=torch.int32)
+    out = DeviceAugment()(torch.from_numpy(rgb).cuda(), torch.from_numpy(dsm).cuda(), torch.from_numpy(lab).cuda(), codes)
+    for t in range(n):
+        c = int(codes[t])
+        a, z, l = R.augment_patch(rgb[t], dsm[t], lab[t], c & 1, (c >> 1) & 1, (c >> 2) & 3)
+        a, z = R.normalise_patch(a, z)
+        assert np.abs(out[0][t].cpu().numpy() - a).max() < 2e-6
+        assert np.abs(out[1][t].cpu().numpy() - z).max() < 1e-6
+        assert np.array_equal(out[2][t].cpu().numpy(), l)
+    c2 = random_codes(4096, torch.Generator().manual_seed(1))
+    assert c2.dtype == torch.int32 and int(c2.max()) < 16 and abs(((c2 >> 2) == 0).float().mean().item() - 0.5) < 0.05
