@@ -68,57 +68,9 @@ struct ColRedParams {
   const float* chan_scale; int64_t rows_per_image;       // optional [B, C] multiplier (Dropout2d mask)
   float* partial; unsigned int* counter;                 // workspace: [G][splits][2][C] floats, [G] zeroed tickets
 };
-__global__ __launch_bounds__(256) void colreduce_kernel(const ColRedParams p) {
-  __shared__ float4 red0[256], red1[256];
+// Finish of a column reduction: red0 / red1 hold the workgroup's per-row-lane partial sums as [nrl][C/4] float4.
+__device__ __forceinline__ void colreduce_finish(const ColRedParams& p, const int64_t g, float4* red0, float4* red1, const int nrl) {
   const int C4 = p.C >> 2;
-  const int cg = threadIdx.x % C4, rl = threadIdx.x / C4, nrl = 256 / C4;
-  const int64_t g = blockIdx.y;
-  const int64_t r0 = (int64_t)blockIdx.x * p.rpb;
-  int64_t r1 = r0 + p.rpb;
-  if (r1 > p.P) r1 = p.P;
-  float4 s0 = F4ZERO, s1 = F4ZERO;
-  float4 mu = F4ZERO, rs = F4ZERO, ga = F4ZERO, be = F4ZERO;
-  if (p.mode == 2) {
-    mu = reinterpret_cast<const float4*>(p.mean)[cg]; rs = reinterpret_cast<const float4*>(p.rstd)[cg];
-    ga = reinterpret_cast<const float4*>(p.gamma)[cg]; be = reinterpret_cast<const float4*>(p.beta)[cg];
-  }
-  if (rl < nrl) {
-    // eight rows per thread are requested before any is consumed: the kernel streams the map once and is bound
-    // by the bytes in flight (rows past the end re-read the last row and are discarded)
-    for (int64_t rb = r0 + rl; rb < r1; rb += 8 * nrl) {
-      float4 av[8], bv[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        int64_t r = rb + (int64_t)k * nrl;
-        r = r < r1 ? r : r1 - 1;
-        const int64_t row = g * p.P + r;
-        av[k] = ld4(p.a, p.a_dt, row * C4 + cg);
-        if (p.mode != 0) bv[k] = ld4(p.b, p.b_dt, row * C4 + cg);
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int64_t r = rb + (int64_t)k * nrl;
-        if (r >= r1) break;
-        const float4 a = av[k];
-        if (p.mode == 0) {
-          s0 = f4add(s0, a); s1 = f4fma(a, a, s1);
-        } else if (p.mode == 1) {
-          s0 = f4fma(a, bv[k], s0);
-        } else {
-          const float4 x = bv[k];
-          const float4 xh = make_float4((x.x - mu.x) * rs.x, (x.y - mu.y) * rs.y, (x.z - mu.z) * rs.z, (x.w - mu.w) * rs.w);
-          float4 d = a;
-          if (p.chan_scale) d = f4mul(d, reinterpret_cast<const float4*>(p.chan_scale)[((g * p.P + r) / p.rows_per_image) * C4 + cg]);
-          if (p.act != ACT_NONE) {
-            d.x *= act_grad_f(fmaf(ga.x, xh.x, be.x), p.act); d.y *= act_grad_f(fmaf(ga.y, xh.y, be.y), p.act);
-            d.z *= act_grad_f(fmaf(ga.z, xh.z, be.z), p.act); d.w *= act_grad_f(fmaf(ga.w, xh.w, be.w), p.act);
-          }
-          s0 = f4add(s0, d); s1 = f4fma(d, xh, s1);
-        }
-      }
-    }
-  }
-  red0[threadIdx.x] = s0; red1[threadIdx.x] = s1;
   __syncthreads();
   // Deterministic finish without float atomics: every workgroup stores its partial row sums, the one that
   // draws the last ticket of its group adds all of them in a fixed order (agent-scope hand-off:
@@ -128,7 +80,9 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const ColRedParams p) {
   const int splits = gridDim.x;
   float* slab = p.partial + ((int64_t)g * splits + blockIdx.x) * 2 * p.C;
   if (threadIdx.x < C4) {
-    for (int k = 1; k < nrl; ++k) { s0 = f4add(s0, red0[k * C4 + cg]); s1 = f4add(s1, red1[k * C4 + cg]); }
+    const int cg = threadIdx.x;
+    float4 s0 = F4ZERO, s1 = F4ZERO;
+    for (int k = 0; k < nrl; ++k) { s0 = f4add(s0, red0[k * C4 + cg]); s1 = f4add(s1, red1[k * C4 + cg]); }
     // write-through (sc1) 8-byte stores: the slab needs no release fence, which would write back every dirty
     // line of this XCD's L2 - typically the map the previous kernel just produced
     typedef __attribute__((address_space(1))) unsigned long long gu64_t;
@@ -184,6 +138,108 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const ColRedParams p) {
     }
   }
 }
+
+__global__ __launch_bounds__(256) void colreduce_kernel(const ColRedParams p) {
+  __shared__ float4 red0[256], red1[256];
+  const int C4 = p.C >> 2;
+  const int cg = threadIdx.x % C4, rl = threadIdx.x / C4, nrl = 256 / C4;
+  const int64_t g = blockIdx.y;
+  const int64_t r0 = (int64_t)blockIdx.x * p.rpb;
+  int64_t r1 = r0 + p.rpb;
+  if (r1 > p.P) r1 = p.P;
+  float4 s0 = F4ZERO, s1 = F4ZERO;
+  float4 mu = F4ZERO, rs = F4ZERO, ga = F4ZERO, be = F4ZERO;
+  if (p.mode == 2) {
+    mu = reinterpret_cast<const float4*>(p.mean)[cg]; rs = reinterpret_cast<const float4*>(p.rstd)[cg];
+    ga = reinterpret_cast<const float4*>(p.gamma)[cg]; be = reinterpret_cast<const float4*>(p.beta)[cg];
+  }
+  if (rl < nrl) {
+    // eight rows per thread are requested before any is consumed: the kernel streams the map once and is bound
+    // by the bytes in flight (rows past the end re-read the last row and are discarded)
+    for (int64_t rb = r0 + rl; rb < r1; rb += 8 * nrl) {
+      float4 av[8], bv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        int64_t r = rb + (int64_t)k * nrl;
+        r = r < r1 ? r : r1 - 1;
+        const int64_t row = g * p.P + r;
+        av[k] = ld4(p.a, p.a_dt, row * C4 + cg);
+        if (p.mode != 0) bv[k] = ld4(p.b, p.b_dt, row * C4 + cg);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int64_t r = rb + (int64_t)k * nrl;
+        if (r >= r1) break;
+        const float4 a = av[k];
+        if (p.mode == 0) {
+          s0 = f4add(s0, a); s1 = f4fma(a, a, s1);
+        } else if (p.mode == 1) {
+          s0 = f4fma(a, bv[k], s0);
+        } else {
+          const float4 x = bv[k];
+          const float4 xh = make_float4((x.x - mu.x) * rs.x, (x.y - mu.y) * rs.y, (x.z - mu.z) * rs.z, (x.w - mu.w) * rs.w);
+          float4 d = a;
+          if (p.chan_scale) d = f4mul(d, reinterpret_cast<const float4*>(p.chan_scale)[((g * p.P + r) / p.rows_per_image) * C4 + cg]);
+          if (p.act != ACT_NONE) {
+            d.x *= act_grad_f(fmaf(ga.x, xh.x, be.x), p.act); d.y *= act_grad_f(fmaf(ga.y, xh.y, be.y), p.act);
+            d.z *= act_grad_f(fmaf(ga.z, xh.z, be.z), p.act); d.w *= act_grad_f(fmaf(ga.w, xh.w, be.w), p.act);
+          }
+          s0 = f4add(s0, d); s1 = f4fma(d, xh, s1);
+        }
+      }
+    }
+  }
+  red0[threadIdx.x] = s0; red1[threadIdx.x] = s1;
+  colreduce_finish(p, g, red0, red1, nrl);
+}
+
+// bf16 maps (SE pools over the FPN levels, their gate gradients, ConvTranspose bias gradients): the same
+// reduction with 16-byte loads - eight columns per thread, modes 0 (sum, sum of squares) and 1 (dot) only.
+__global__ __launch_bounds__(256) void colreduce_wide_kernel(const ColRedParams p) {
+  __shared__ float4 red0[512], red1[512];
+  const int CG = p.C >> 3;
+  const int cg = threadIdx.x % CG, rl = threadIdx.x / CG, nrl = 256 / CG;
+  const int64_t g = blockIdx.y;
+  const int64_t r0 = (int64_t)blockIdx.x * p.rpb;
+  int64_t r1 = r0 + p.rpb;
+  if (r1 > p.P) r1 = p.P;
+  float s0[8], s1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+  const u32x4_t* A = reinterpret_cast<const u32x4_t*>(p.a);
+  const u32x4_t* B = reinterpret_cast<const u32x4_t*>(p.b);
+  for (int64_t rb = r0 + rl; rl < nrl && rb < r1; rb += 8 * nrl) {
+    u32x4_t av[8], bv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int64_t r = rb + (int64_t)k * nrl;
+      r = r < r1 ? r : r1 - 1;
+      av[k] = A[(g * p.P + r) * CG + cg];
+      if (p.mode == 1) bv[k] = B[(g * p.P + r) * CG + cg];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (rb + (int64_t)k * nrl >= r1) break;
+      const unsigned int aw[4] = {av[k].x, av[k].y, av[k].z, av[k].w};
+      const unsigned int bw[4] = {bv[k].x, bv[k].y, bv[k].z, bv[k].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = bf16_lo(aw[e]), hi = bf16_hi(aw[e]);
+        if (p.mode == 0) {
+          s0[2 * e] += lo; s0[2 * e + 1] += hi;
+          s1[2 * e] = fmaf(lo, lo, s1[2 * e]); s1[2 * e + 1] = fmaf(hi, hi, s1[2 * e + 1]);
+        } else {
+          s0[2 * e] = fmaf(lo, bf16_lo(bw[e]), s0[2 * e]); s0[2 * e + 1] = fmaf(hi, bf16_hi(bw[e]), s0[2 * e + 1]);
+        }
+      }
+    }
+  }
+  // [rl][C/4] float4 layout: this thread owns float4 columns 2*cg and 2*cg + 1 of row lane rl
+  red0[2 * threadIdx.x] = make_float4(s0[0], s0[1], s0[2], s0[3]); red0[2 * threadIdx.x + 1] = make_float4(s0[4], s0[5], s0[6], s0[7]);
+  red1[2 * threadIdx.x] = make_float4(s1[0], s1[1], s1[2], s1[3]); red1[2 * threadIdx.x + 1] = make_float4(s1[4], s1[5], s1[6], s1[7]);
+  colreduce_finish(p, g, red0, red1, nrl);
+}
+
 static int64_t colreduce_splits(int64_t G, int64_t P, int C, int64_t* rpb_out) {
   int64_t splits = ceil_div64(512, G);
   if (splits > 128) splits = 128;                    // the last arriver reads every slab (long-latency loads)
@@ -205,7 +261,10 @@ static int launch_colreduce(ColRedParams& p, int64_t G, float* workspace, unsign
   int64_t rpb;
   const int64_t splits = colreduce_splits(G, p.P, p.C, &rpb);
   p.rpb = rpb; p.partial = workspace; p.counter = counters;
-  hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)splits, (unsigned)G), dim3(256), 0, stream, p);
+  const bool wide = p.a_dt == MFNET_BF16 && (p.mode == 0 || (p.mode == 1 && p.b_dt == MFNET_BF16)) && p.C % 8 == 0 && ((uintptr_t)p.a % 16 == 0) &&
+                    (p.mode == 0 || (uintptr_t)p.b % 16 == 0);
+  if (wide) hipLaunchKernelGGL(colreduce_wide_kernel, dim3((unsigned)splits, (unsigned)G), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)splits, (unsigned)G), dim3(256), 0, stream, p);
   MF_LAUNCH_CHECK(who);
   return MFNET_OK;
 }
