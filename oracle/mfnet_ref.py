@@ -531,3 +531,58 @@ def normalise_patch(data, dsm, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.
     if z.max() > z.min():
         z = (z - z.min()) / (z.max() - z.min())
     return d.astype(np.float32), z.astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# inference.py pre / post steps around the tile loop - numpy, the reference's statements in the reference's order
+def normalize_image(image, is_rgb=True, nodata_value=None):
+    """BuildingInference._normalize_image (inference.py:444-496): -> (fp32 image, bool nodata mask [H,W]).
+    The percentile scalars are cast to fp32 before they meet the fp32 array, which is what numpy 1.24 (the
+    reference's pin, environment.yml:19) does through value-based casting."""
+    import numpy as np
+    if nodata_value is not None:
+        nodata_mask = np.any(image == nodata_value, axis=0) if image.ndim > 2 else (image == nodata_value)
+    else:
+        nodata_mask = np.zeros(image.shape[-2:], dtype=bool)
+    out = image.copy().astype(np.float32)
+    if is_rgb:
+        if image.dtype == np.uint8:
+            out = out / np.float32(255.0)
+        elif image.dtype == np.uint16:
+            out = out / np.float32(65535.0)
+        elif np.any(~nodata_mask):
+            valid = out[:, ~nodata_mask] if out.ndim > 2 else out[~nodata_mask]
+            p2, p98 = np.percentile(valid, (2, 98))
+            out = np.clip((out - np.float32(p2)) / np.float32(p98 - p2), 0, 1).astype(np.float32)
+        else:
+            out = np.clip(out, 0, 1)
+        if out.ndim == 3 and out.shape[0] == 3:
+            mean = np.array([0.485, 0.456, 0.406], dtype=np.float32)[:, None, None]
+            std = np.array([0.229, 0.224, 0.225], dtype=np.float32)[:, None, None]
+            out = (out - mean) / std
+    if out.ndim > 2:
+        out[:, nodata_mask] = 0
+    else:
+        out[nodata_mask] = 0
+    return out, nodata_mask
+
+
+def tile_vector_masks(forward, rgb, dem, window=(256, 256), overlap_px=64, threshold=0.5, cls=1):
+    """Tile loop of _tile_by_tile_vector_inference (inference.py:713-757) up to the vectoriser's input: per window
+    reflect-pad (:726-737), per-tile DEM min-max (:547-555), softmax(logits)[cls] (:562-566), crop (:742-744) and
+    `prediction >= threshold` (:582). rgb [3,H,W] normalised fp32 numpy, dem [H,W] raw. -> [(window, prob, mask)]"""
+    import numpy as np
+    out = []
+    for (y, x, ye, xe) in inference_windows(rgb.shape[1], rgb.shape[2], window, overlap_px):
+        wh, ww = ye - y, xe - x
+        ph, pw = max(0, window[0] - wh), max(0, window[1] - ww)
+        rp, dp = rgb[:, y:ye, x:xe], dem[None, y:ye, x:xe]
+        if ph > 0 or pw > 0:
+            rp = np.pad(rp, ((0, 0), (0, ph), (0, pw)), mode="reflect")
+            dp = np.pad(dp, ((0, 0), (0, ph), (0, pw)), mode="reflect")
+        d = dp[0].astype(np.float32)
+        d = (d - d.min()) / (d.max() - d.min()) if d.max() > d.min() else np.zeros_like(d)
+        logits = forward(torch.from_numpy(np.ascontiguousarray(rp))[None], torch.from_numpy(d)[None])
+        prob = torch.softmax(logits, dim=1)[0, cls].numpy()[:wh, :ww]
+        out.append(((y, x, ye, xe), prob, (prob >= threshold).astype(np.uint8)))
+    return out

@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 # torch must be loaded FIRST: it ships its own libamdhip64.so.7 and owns the device memory and streams
 # this library works on. Loading libmfnet_hip.so before torch would bind the process to the system HIP
@@ -25,7 +25,7 @@ class MfnetError(RuntimeError):
 
 _lib = None
 
-P, I64, I, F = c_void_p, c_int64, c_int, c_float
+P, I64, I, F, D = c_void_p, c_int64, c_int, c_float, c_double
 
 # name -> argtypes (all return int status); mirrors include/mfnet_hip.h
 _SIGS = {
@@ -96,6 +96,8 @@ _SIGS = {
     "mfnet_tile_minmax_norm": [P, I64, I64, I, P],
     "mfnet_tile_prob_accumulate": [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, P],
     "mfnet_blend_finish": [P, P, P, P, F, I64, P],
+    "mfnet_normalize_raster": [P, I, I64, I64, I64, I, I, F, F, P, P, I, D, P, P, P],
+    "mfnet_tile_prob_mask": [P, P, P, P, I64, I64, I64, I64, I64, F, P],
     "mfnet_confusion": [P, P, P, I64, I64, P],
 }
 

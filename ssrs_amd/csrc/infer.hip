@@ -114,14 +114,14 @@ extern "C" int mfnet_tile_prob_accumulate(float* sum, float* cnt, const float* l
   MF_LAUNCH_CHECK("tile_prob_accumulate");
   return MFNET_OK;
 }
-// prob = sum / cnt (0 where no tile covers the pixel) ; mask = prob > threshold
+// prob = sum / cnt (0 where no tile covers the pixel) ; mask = prob >= threshold (inference.py:582)
 __global__ __launch_bounds__(256) void blend_finish_kernel(const float* __restrict__ sum, const float* __restrict__ cnt, float* __restrict__ prob,
                                                            unsigned char* __restrict__ mask, float thr, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float c = cnt[i];
     const float p = c > 0.f ? sum[i] / c : 0.f;
     if (prob) prob[i] = p;
-    if (mask) mask[i] = p > thr ? 1 : 0;
+    if (mask) mask[i] = p >= thr ? 1 : 0;
   }
 }
 extern "C" int mfnet_blend_finish(const float* sum, const float* cnt, float* prob, unsigned char* mask, float threshold, int64_t n, hipStream_t stream) {
@@ -129,6 +129,87 @@ extern "C" int mfnet_blend_finish(const float* sum, const float* cnt, float* pro
   if (n == 0) return MFNET_OK;
   hipLaunchKernelGGL(blend_finish_kernel, dim3(grid_for(n)), dim3(256), 0, stream, sum, cnt, prob, mask, threshold, n);
   MF_LAUNCH_CHECK("blend_finish");
+  return MFNET_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// BuildingInference._normalize_image (inference.py:444-496) on a whole raster [C,H,W] of uint8 / uint16 / fp32:
+//   nodata[y,x] = any_c(in[c,y,x] == nodata_value)                                       (:456-459)
+//   RGB:  u = in / 255 (uint8) | in / 65535 (uint16) | clip((in - p2) / (p98 - p2), 0, 1) (fp32; the percentiles
+//         come from the host side), then (u - mean[c]) / std[c] when C == 3               (:464-484)
+//   DEM:  the raw value as fp32                                                           (:485-488)
+//   nodata pixels are set to 0 in every channel                                           (:490-494)
+// Divisions are IEEE fp32 divisions as in numpy (no reciprocal), so the result is bit-equal to the reference's.
+struct RasterNorm { float sub, div, mean[3], stdv[3]; int scale, clip, imagenet, has_nodata; double nodata; };
+template <typename T>
+__global__ __launch_bounds__(256) void normalize_raster_kernel(const T* __restrict__ in, float* __restrict__ out, unsigned char* __restrict__ mask,
+                                                               int64_t hw, int C, RasterNorm rp) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256) {
+    bool nd = false;
+    if (rp.has_nodata)
+      for (int c = 0; c < C; ++c) nd = nd || ((double)in[(int64_t)c * hw + i] == rp.nodata);
+    if (mask) mask[i] = nd ? 1 : 0;
+    for (int c = 0; c < C; ++c) {
+      float u = (float)in[(int64_t)c * hw + i];
+      if (rp.scale) {
+        if (rp.clip) { u = (u - rp.sub) / rp.div; u = u < 0.f ? 0.f : (u > 1.f ? 1.f : u); }   // keeps a NaN, like np.clip
+        else u = u / rp.div;
+      }
+      if (rp.imagenet) u = (u - rp.mean[c]) / rp.stdv[c];
+      out[(int64_t)c * hw + i] = nd ? 0.f : u;
+    }
+  }
+}
+extern "C" int mfnet_normalize_raster(const void* in, int in_kind, int64_t C, int64_t H, int64_t W, int is_rgb, int clip, float sub,
+                                      float div, const float* mean3, const float* std3, int has_nodata, double nodata_value,
+                                      float* out, unsigned char* nodata_mask, hipStream_t stream) {
+  MF_CHECK_ARG(in && out && C > 0 && C <= 16 && H > 0 && W > 0, "normalize_raster: bad args (1 <= C <= 16)");
+  MF_CHECK_ARG(in_kind >= 0 && in_kind <= 2, "normalize_raster: in_kind is 0 (uint8), 1 (uint16) or 2 (fp32)");
+  RasterNorm rp{};
+  rp.scale = is_rgb ? 1 : 0; rp.clip = clip ? 1 : 0; rp.sub = sub; rp.div = div;
+  rp.has_nodata = has_nodata ? 1 : 0; rp.nodata = nodata_value;
+  MF_CHECK_ARG(!is_rgb || clip || div != 0.f, "normalize_raster: zero divisor");
+  rp.imagenet = (is_rgb && C == 3 && mean3 && std3) ? 1 : 0;
+  if (rp.imagenet)
+    for (int c = 0; c < 3; ++c) { rp.mean[c] = mean3[c]; rp.stdv[c] = std3[c]; }
+  const dim3 grid(grid_for(H * W));
+  if (in_kind == 0) hipLaunchKernelGGL(normalize_raster_kernel<unsigned char>, grid, dim3(256), 0, stream, (const unsigned char*)in, out, nodata_mask, H * W, (int)C, rp);
+  else if (in_kind == 1) hipLaunchKernelGGL(normalize_raster_kernel<unsigned short>, grid, dim3(256), 0, stream, (const unsigned short*)in, out, nodata_mask, H * W, (int)C, rp);
+  else hipLaunchKernelGGL(normalize_raster_kernel<float>, grid, dim3(256), 0, stream, (const float*)in, out, nodata_mask, H * W, (int)C, rp);
+  MF_LAUNCH_CHECK("normalize_raster");
+  return MFNET_OK;
+}
+
+// Per-tile building mask for the CPU vectoriser (inference.py:562-566, 582, 742-744): prob = softmax(logits[t])[cls],
+// mask = prob >= threshold over the tile's valid extent (the reflect padding is cropped away: 0 outside).
+__global__ __launch_bounds__(256) void tile_prob_mask_kernel(const float* __restrict__ logits, const int* __restrict__ coords, float* __restrict__ prob,
+                                                             unsigned char* __restrict__ mask, int64_t n, int C, int h, int w, int cls, float thr) {
+  const int64_t per = (int64_t)h * w, total = n * per;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / per;
+    const int64_t r = i - t * per;
+    const int y = (int)(r / w), x = (int)(r - (int64_t)y * w);
+    const int* cd = coords + 4 * t;
+    float pr = 0.f;
+    bool inside = y < cd[2] && x < cd[3];
+    if (inside) {
+      const float* lp = logits + t * C * per + r;
+      float mx = -FLT_MAX;
+      for (int c = 0; c < C; ++c) mx = fmaxf(mx, lp[(int64_t)c * per]);
+      float se = 0.f;
+      for (int c = 0; c < C; ++c) se += __expf(lp[(int64_t)c * per] - mx);
+      pr = __expf(lp[(int64_t)cls * per] - mx) / se;
+    }
+    if (prob) prob[i] = pr;
+    mask[i] = (inside && pr >= thr) ? 1 : 0;
+  }
+}
+extern "C" int mfnet_tile_prob_mask(const float* logits, const int* coords, float* prob, unsigned char* mask, int64_t n, int64_t C,
+                                    int64_t h, int64_t w, int64_t cls, float threshold, hipStream_t stream) {
+  MF_CHECK_ARG(logits && coords && mask && C > 0 && cls >= 0 && cls < C && h > 0 && w > 0, "tile_prob_mask: bad args");
+  if (n <= 0) return MFNET_OK;
+  hipLaunchKernelGGL(tile_prob_mask_kernel, dim3(grid_for(n * h * w)), dim3(256), 0, stream, logits, coords, prob, mask, n, (int)C, (int)h, (int)w, (int)cls, threshold);
+  MF_LAUNCH_CHECK("tile_prob_mask");
   return MFNET_OK;
 }
 

@@ -227,12 +227,46 @@ class RasterInference:
         self.overlap = int(self.window_size[0] * overlap_ratio)                 # inference.py:139-141
         self.batch_size, self.cls, self.threshold, self.group = batch_size, building_class, threshold, group
 
+    @staticmethod
+    def normalize_image(image: torch.Tensor, is_rgb: bool = True, nodata_value=None):
+        """`_normalize_image` (inference.py:444-496) on the device: -> (fp32 image, bool nodata mask [H,W])."""
+        return ops.normalize_raster(image, is_rgb, nodata_value)
+
+    @staticmethod
+    def _rgb(rgb):
+        return ops.normalize_raster(rgb, True, None)[0] if rgb.dtype in (torch.uint8, torch.uint16) else rgb.float().contiguous()
+
+    @torch.no_grad()
+    def predict_tiles(self, rgb: torch.Tensor, dem: torch.Tensor, want_prob: bool = False):
+        """The reference's own post step (`_tile_by_tile_vector_inference`, inference.py:713-757): per window, in the
+        reference's window order, yields `((y, x, y_end, x_end), mask uint8 [wh, ww] numpy[, prob fp32 numpy])` with
+        mask = softmax(logits)[building] >= threshold, cropped to the window - the input of `_create_tile_vectors`.
+        Only the uint8 masks cross to the host (one copy per batch); ranks take contiguous slices of the window list."""
+        h, w = self.window_size
+        img = self._rgb(rgb)
+        _, H, W = img.shape
+        demc = dem.float().contiguous()
+        rank, world = _dist_info(self.group)
+        wins = get_sliding_windows(H, W, self.window_size, self.overlap)
+        per = (len(wins) + world - 1) // world
+        for chunk in grouper(self.batch_size, wins[rank * per:(rank + 1) * per]):
+            c4 = torch.tensor([(y, x, ye - y, xe - x) for y, x, ye, xe in chunk], dtype=torch.int32, device=img.device)
+            rgb_t, dem_t = ops.extract_tiles(img, demc, c4, h, w)
+            ops.tile_minmax_norm(dem_t)
+            logits = self.forward(rgb_t, dem_t).float().contiguous()
+            prob, mask = ops.tile_prob_mask(logits, c4, self.cls, self.threshold, want_prob)
+            mask_h = mask.cpu().numpy()
+            prob_h = prob.cpu().numpy() if want_prob else None
+            for i, (y, x, ye, xe) in enumerate(chunk):
+                m = mask_h[i, :ye - y, :xe - x]
+                yield ((y, x, ye, xe), m, prob_h[i, :ye - y, :xe - x]) if want_prob else ((y, x, ye, xe), m)
+
     @torch.no_grad()
     def predict(self, rgb: torch.Tensor, dem: torch.Tensor):
         """rgb [3,H,W] uint8 (or fp32 already normalised), dem [H,W] fp32 raw, both on the device.
         -> (prob [H,W] fp32: mean building probability over the covering tiles, mask [H,W] uint8)."""
         h, w = self.window_size
-        img = ops.normalize_rgb_u8(rgb.contiguous()) if rgb.dtype == torch.uint8 else rgb.float().contiguous()
+        img = self._rgb(rgb)
         _, H, W = img.shape
         rank, world = _dist_info(self.group)
         wins = get_sliding_windows(H, W, self.window_size, self.overlap)

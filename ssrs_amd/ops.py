@@ -753,6 +753,80 @@ def blend_finish(psum, cnt, threshold):
     return prob, mask
 
 
+def percentiles_2_98(values):
+    """np.percentile(values, (2, 98)) ('linear' method) of a 1-D fp32 device tensor: one device sort, the two
+    neighbours of each virtual index are interpolated on the host the way numpy's _lerp does (inference.py:474)."""
+    import numpy as np
+    v = torch.sort(values.reshape(-1).float()).values
+    n = v.numel()
+    out = []
+    for q in (2.0, 98.0):
+        vi = (q / 100.0) * (n - 1)
+        lo = min(max(int(np.floor(vi)), 0), n - 1)
+        hi = min(lo + 1, n - 1)
+        a, b = (np.float32(x) for x in v[[lo, hi]].tolist())
+        t = vi - lo
+        d = np.float64(np.float32(b - a))                  # numpy's _lerp takes b - a in the array's dtype
+        r = np.float64(a) + d * t if t < 0.5 else np.float64(b) - d * (1 - t)
+        out.append(float(r))
+    return out[0], out[1]
+
+
+def normalize_raster(image, is_rgb=True, nodata_value=None, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """BuildingInference._normalize_image (inference.py:444-496) on the device. image: [C,H,W] or [H,W], uint8 / uint16 /
+    floating -> (fp32 image of the same shape, bool nodata mask [H,W])."""
+    import ctypes
+    _chk(image)
+    img = image.contiguous()
+    chw = img if img.dim() == 3 else img.unsqueeze(0)
+    C, H, W = chw.shape
+    kind = {torch.uint8: 0, torch.uint16: 1}.get(chw.dtype, 2)
+    if kind == 2 and chw.dtype != torch.float32:
+        chw = chw.float()
+    mask = torch.empty((H, W), dtype=torch.uint8, device=img.device)
+    out = torch.empty((C, H, W), dtype=torch.float32, device=img.device)
+    has_nd = nodata_value is not None
+    nd = float(nodata_value) if has_nd else 0.0
+    if has_nd and kind == 2:
+        import numpy as np
+        nd = float(np.float32(nd))                                  # numpy compares an fp32 array with the scalar as fp32
+    clip, sub, div = 0, 0.0, 1.0
+    if is_rgb:
+        if kind == 0:
+            div = 255.0
+        elif kind == 1:
+            div = 65535.0
+        else:                                                          # :471-477 percentile stretch over the valid pixels
+            clip = 1
+            if has_nd:
+                valid = ~(chw == nd).any(dim=0)
+                vals = chw[:, valid]
+            else:
+                vals = chw
+            if vals.numel() > 0:
+                import numpy as np
+                p2, p98 = percentiles_2_98(vals)
+                # numpy 1.24 (the reference's pin) casts the float64 scalars to the array's fp32 (value-based casting)
+                sub, div = float(np.float32(p2)), float(np.float32(p98 - p2))
+    m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    call("mfnet_normalize_raster", chw.data_ptr(), kind, C, H, W, 1 if is_rgb else 0, clip, float(sub), float(div),
+         ctypes.cast(m3, ctypes.c_void_p), ctypes.cast(s3, ctypes.c_void_p), 1 if has_nd else 0, nd, out.data_ptr(), mask.data_ptr(),
+         _stream(img))
+    return (out if img.dim() == 3 else out[0]), mask.bool()
+
+
+def tile_prob_mask(logits, coords4, cls, threshold, want_prob=False):
+    """logits [n,C,h,w] fp32, coords4 [n,4] int32 -> (prob [n,h,w] | None, mask uint8 [n,h,w]); 0 outside each tile's extent."""
+    _chk(logits, coords4)
+    assert logits.is_contiguous() and logits.dtype == torch.float32 and coords4.dtype == torch.int32 and coords4.is_contiguous()
+    n, C, h, w = logits.shape
+    assert coords4.shape[0] == n
+    prob = torch.empty((n, h, w), dtype=torch.float32, device=logits.device) if want_prob else None
+    mask = torch.empty((n, h, w), dtype=torch.uint8, device=logits.device)
+    call("mfnet_tile_prob_mask", logits.data_ptr(), coords4.data_ptr(), _p(prob), mask.data_ptr(), n, C, h, w, int(cls), float(threshold), _stream(logits))
+    return prob, mask
+
+
 def confusion(pred_u8, gt_i64, n_classes):
     _chk(pred_u8, gt_i64)
     assert pred_u8.dtype == torch.uint8 and gt_i64.dtype == torch.int64 and pred_u8.is_contiguous() and gt_i64.is_contiguous()

@@ -88,7 +88,49 @@ def test_raster_inference_blend_vs_numpy():
         psum[y:ye, x:xe] += pr; cnt[y:ye, x:xe] += 1
     ref = np.where(cnt > 0, psum / np.maximum(cnt, 1), 0)
     assert np.abs(prob.cpu().numpy() - ref).max() < 1e-5
-    assert (mask.cpu().numpy() == (ref > 0.5)).mean() > 0.9999
+    assert (mask.cpu().numpy() == (ref >= 0.5)).mean() > 0.9999
+
+
+def test_normalize_raster_is_bit_equal_to_numpy_restatement():
+    """_normalize_image (inference.py:444-496): uint8 / uint16 / fp32-percentile RGB, raw DEM, nodata masks; the
+    device result is bit-equal to the numpy statements (IEEE fp32 divisions on both sides)."""
+    from ssrs_amd import ops
+    H, W = 97, 211
+    u = (detfill.uniform("nr/rgb", (3, H, W)) + 1) * 0.5
+    cases = [((u * 255).astype(np.uint8), True, 0), ((u * 255).astype(np.uint8), True, None), ((u * 65535).astype(np.uint16), True, 0),
+             ((u * 900 - 50).astype(np.float32), True, None), ((u * 900 - 50).astype(np.float32), True, -9999.0),
+             ((u[0] * 300 + 20).astype(np.float32), False, -9999), ((u[:2] * 255).astype(np.uint8), True, 3)]
+    for k, (img, is_rgb, nd) in enumerate(cases):
+        img = img.copy()
+        if nd is not None:
+            img[..., 5:9, 10:40] = nd                                   # a nodata block (in every channel)
+            if img.ndim == 3:
+                img[0, 50, 60] = nd                                    # and a pixel where a single channel hits it
+        ref, ref_mask = R.normalize_image(img, is_rgb, nd)
+        t = torch.from_numpy(img.view(np.int16)).view(torch.uint16) if img.dtype == np.uint16 else torch.from_numpy(img)
+        out, mask = ops.normalize_raster(t.cuda(), is_rgb, nd)
+        assert out.dtype == torch.float32 and tuple(out.shape) == img.shape, k
+        assert np.array_equal(mask.cpu().numpy(), ref_mask), k
+        assert np.array_equal(out.cpu().numpy(), ref), (k, np.abs(out.cpu().numpy() - ref).max())
+
+
+def test_tile_masks_for_the_vectoriser_match_reference_loop():
+    """predict_tiles: the reference's per-tile outputs (cropped softmax probability and `>= threshold` mask,
+    inference.py:562-566, 582, 742-744) in the reference's window order."""
+    from ssrs_amd.inference import RasterInference
+    H, W = 383, 200
+    rgb = ((detfill.uniform("rinf/rgb", (3, H, W)) + 1) * 127.5).astype(np.uint8)
+    dem = (100 + 30 * detfill.uniform("rinf/dem", (H, W))).astype(np.float32)
+    dem[:40, :] = 7.0
+    ri = RasterInference(_standin, (256, 256), overlap_ratio=0.5, batch_size=3, threshold=0.55)
+    got = list(ri.predict_tiles(torch.from_numpy(rgb).cuda(), torch.from_numpy(dem).cuda(), want_prob=True))
+    ref = R.tile_vector_masks(_standin, R.normalize_image(rgb, True, None)[0], dem, (256, 256), 128, 0.55, 1)
+    assert len(got) == len(ref) >= 2
+    for (wg, mg, pg), (wr, pr, mr) in zip(got, ref):
+        assert tuple(wg) == tuple(wr) and mg.shape == mr.shape and mg.dtype == np.uint8
+        assert np.abs(pg - pr).max() < 1e-5
+        sure = np.abs(pr - 0.55) > 1e-5                                  # away from the threshold the masks are equal
+        assert np.array_equal(mg[sure], mr[sure]) and (mg == mr).mean() > 0.999
 
 
 def test_train_engine_two_steps_vs_reference_losses():
