@@ -106,10 +106,38 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a ROCm GPU: the MFNet hot path has no CPU fallback")
+    # MFNET_BENCH_REHEARSAL (developer aid on a one-GPU box; the numbers of such a run mean nothing):
+    #   gloo  - N ranks share the visible GPUs and exchange over gloo through host copies: walks the N>1 control flow
+    #   nccl1 - one rank, RCCL initialised with world size 1, the engine still issues its all-reduces: walks the
+    #           RCCL + HIP-graph sequence of a step on a real GPU
+    rehearsal = os.environ.get("MFNET_BENCH_REHEARSAL", "")
+    if rehearsal:
+        import faulthandler
+        faulthandler.dump_traceback_later(120, exit=True)         # a hang names its line instead of idling
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    if rehearsal == "gloo":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        real_all_reduce = dist.all_reduce
+
+        class _Done:
+            def wait(self):
+                return True
+
+        def staged_all_reduce(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
+            h = t.detach().cpu()
+            real_all_reduce(h, op=op, group=group)
+            t.copy_(h)
+            return _Done() if async_op else None
+        dist.all_reduce = staged_all_reduce
+    elif rehearsal == "nccl1":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    elif world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -117,7 +145,7 @@ def main():
     from ssrs_amd.trainer import TrainEngine
     model = build_model(a.mod, a.encoder, a.classes, dev)
     eng = TrainEngine(model, lr=0.01, momentum=0.9, weight_decay=5e-4, class_weight=torch.ones(a.classes, device=dev),
-                      use_graph=not a.eager)
+                      use_graph=not a.eager, exchange_when_alone=rehearsal == "nccl1")
     rgb, dsm, tgt = detfill.tiles(f"bench/rank{rank}", a.batch, a.tile, a.classes)
     rgb, dsm, tgt = rgb.to(dev), dsm.to(dev), tgt.to(dev)
 
@@ -141,14 +169,16 @@ def main():
     metrics = TrainEngine.read_metrics(acc)
 
     roofline = None
-    if rank == 0 and not a.no_roofline:
-        # second pass over the same steps, eagerly, with an event pair around every GEMM launch
+    if not a.no_roofline:
+        # second pass over the same steps, eagerly, with an event pair around every GEMM launch. Every rank takes
+        # it (the steps contain the gradient all-reduce, a collective); rank 0's launches are the ones reported.
         eng.use_graph = False
         ops.GEMM_TRACE = []
         for _ in range(a.steps):
             eng.step(rgb, dsm, tgt)
         torch.cuda.synchronize()
         tr, ops.GEMM_TRACE = ops.GEMM_TRACE, None
+    if rank == 0 and not a.no_roofline:
         # an event pair with nothing between its two records still reads a few microseconds apart; that offset
         # (median of 64 empty pairs) is taken off every launch so the figure agrees with rocprofv3's kernel durations
         empty = []
@@ -199,10 +229,12 @@ def main():
                                             if a.encoder == "vit_b" and a.tile == 256 else None)}
         if roofline is not None:
             out["roofline"] = roofline
+        if rehearsal:
+            out["rehearsal"] = rehearsal + ": control-flow check only, not a measurement"
         if world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(a.mod, a.encoder, a.classes)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

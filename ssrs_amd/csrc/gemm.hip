@@ -84,8 +84,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = wave * 32 + i * 8 + srow;
+#ifdef GEMM_EXP_SAMETILE
+    int gm = row, gn = row;
+#else
     int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
     int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
+#endif
     const int ca = sch ^ swz_x(row), cw = sch ^ swz_w(row);
     a_src[i] = p.A + (int64_t)gm * p.lda + (ca << 3);
     w_src[i] = p.W + (int64_t)gn * p.ldw + (cw << 3);

@@ -83,8 +83,10 @@ class TrainEngine:
 
     def __init__(self, model: nn.Module, lr: float = 0.01, momentum: float = 0.9, weight_decay: float = 5e-4,
                  milestones: Sequence[int] = (25, 35, 45), gamma: float = 0.1, class_weight: Optional[torch.Tensor] = None,
-                 ignore_index: int = -100, process_group=None, overlap: bool = True, use_graph: bool = False):
+                 ignore_index: int = -100, process_group=None, overlap: bool = True, use_graph: bool = False,
+                 exchange_when_alone: bool = False):
         self.model = model
+        self.exchange_when_alone = bool(exchange_when_alone)      # world 1 still calls the collective (rehearsals)
         self.base_lr, self.momentum, self.weight_decay = float(lr), float(momentum), float(weight_decay)
         self.milestones, self.gamma = sorted(int(m) for m in milestones), float(gamma)
         self.epoch = 0
@@ -162,7 +164,7 @@ class TrainEngine:
         self._works.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def _finish_exchange(self):
-        if self.world == 1:
+        if self.world == 1 and not (self.exchange_when_alone and dist.is_initialized()):
             return
         if not self.overlap or any(c != s for c, s in zip(self._pending, self._bucket_size)):
             # a bucket whose hooks did not all fire (a tensor without gradient this step) is reduced whole
@@ -216,7 +218,9 @@ class TrainEngine:
             srgb, sdsm, stgt = rgb.clone(), dsm.clone(), target.clone()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: RCCL's watchdog thread polls its events while this thread captures; under the default
+            # (global) mode that poll is an illegal call during capture and takes the process down
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.zero_grad()
                 acc, _ = self.forward_backward(srgb, sdsm, stgt)
             ent = self._graphs[key] = (g, srgb, sdsm, stgt, acc)

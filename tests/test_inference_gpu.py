@@ -183,6 +183,34 @@ def test_train_engine_graph_mode_matches_eager():
     assert losses[True][-1] < losses[True][0]
 
 
+def test_train_engine_graph_mode_with_rccl_exchange():
+    """The data-parallel sequence of a step on a real GPU: RCCL initialised (world size 1 - one GPU here), the engine
+    still issues its bucketed all-reduces after every graph replay. Capturing the graph while RCCL's watchdog thread
+    polls its events must not abort (thread-local capture mode), and the trajectory equals the single-process one."""
+    import os
+    import torch.distributed as dist
+    from ssrs_amd.trainer import TrainEngine
+    rgb, dsm, tgt = [t.cuda() for t in detfill.tiles("graph", 2, 256, 6)]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        losses = {}
+        for alone in (False, True):
+            m = _tiny()
+            m.load_state_dict(detfill.fill_state_dict(m.state_dict(), "graph/"))
+            m = m.cuda().train()
+            m.decoder.segmentation_head[1].p = 0.0
+            eng = TrainEngine(m, lr=0.01, momentum=0.9, weight_decay=5e-4, class_weight=torch.ones(6, device="cuda"), use_graph=True,
+                              exchange_when_alone=alone)
+            losses[alone] = [TrainEngine.read_metrics(eng.step(rgb, dsm, tgt))["loss"] for _ in range(5)]
+            assert len(eng._graphs) == 1 and not eng._works
+        for a, b in zip(losses[False], losses[True]):
+            assert abs(a - b) < 2e-3 * abs(a), losses
+    finally:
+        dist.destroy_process_group()
+
+
 def test_engine_gradients_equal_plain_autograd_and_bank_is_never_stale():
     """The engine's step-scoped plumbing (parameter bank, direct gradient delivery, zero arena) changes no
     arithmetic: the flat gradient buffer after forward_backward equals the gradients plain autograd returns for
