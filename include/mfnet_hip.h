@@ -200,6 +200,12 @@ int mfnet_colsum(const void* x, int x_dtype, float* sum, float* sumsq, int64_t G
                  float* workspace, unsigned int* tickets, hipStream_t stream);
 int mfnet_coldot(const void* a, int a_dtype, const void* b, int b_dtype, float* out, int64_t G, int64_t P, int64_t C,
                  float* workspace, unsigned int* tickets, hipStream_t stream);
+/* LayerNorm weight gradients, deterministic: dbeta [C] += sum_rows dy ; dgamma [C] += sum_rows dy * (x - mean[row]) * rstd[row]
+ * (the affine parameters of nn.LayerNorm / Norm2d, unetformer_mmsam.py:14-22, 499-503). dy / x are contiguous [rows, C]
+ * (ld == C); workspace = mfnet_colreduce_workspace_floats(1, rows, C) floats and one zeroed ticket. */
+int mfnet_layernorm_bwd_weights(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd,
+                                float* dgamma, float* dbeta, int64_t rows, int64_t C, float* workspace, unsigned int* tickets,
+                                hipStream_t stream);
 
 /* nn.BatchNorm2d (:27-73,126-129,508). finalize: training != 0: mean / rstd from the batch sums (biased
  * variance), running_mean / running_var updated with `momentum` (unbiased variance), num_batches_tracked += 1;

@@ -85,7 +85,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIn* __restrict__ x, 
 
 // dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)) [+ dres]; optional bf16 copy of dx;
 // optional dgamma/dbeta accumulation (float atomics, one add per column per wave).
-template <typename TDy, typename TX>
+// NVL = float4 chunks per lane (C <= 256 * NVL): the per-row register arrays are sized for the row at hand, which keeps
+// enough waves resident for the loads in flight to cover HBM latency (sized for C = 2048 the kernel ran 2 waves / SIMD).
+template <typename TDy, typename TX, int NVL, bool WANT_W>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy, int64_t lddy,
                                                      const TX* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ mean,
@@ -98,21 +100,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int nv = C >> 2;
-  float4 ag[LN_MAXV], ab[LN_MAXV];
-  const bool want_w = dgamma != nullptr;
+  float4 ag[NVL], ab[NVL];
+  constexpr bool want_w = WANT_W;
   if (want_w) {
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NVL; ++i) {
       ag[i] = make_float4(0, 0, 0, 0);
       ab[i] = make_float4(0, 0, 0, 0);
     }
   }
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
     const float mu = mean[row], rs = rstd[row];
-    float4 xh[LN_MAXV], gd[LN_MAXV];
+    float4 xh[NVL], gd[NVL], rr[NVL];
     float s1 = 0.f, s2 = 0.f;
+    if (dres) {        // requested with x and dy: the row costs one memory round trip, not two
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+      for (int i = 0; i < NVL; ++i) {
+        const int c4 = lane + 64 * i;
+        if (c4 < nv) rr[i] = *reinterpret_cast<const float4*>(dres + row * lddx + 4 * c4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
       const int c4 = lane + 64 * i;
       if (c4 < nv) {
         const float4 xv = ld4<TX>(x + row * ldx + 4 * c4);
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
     const float m1 = wave_sum(s1) / (float)C;
     const float m2 = wave_sum(s2) / (float)C;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NVL; ++i) {
       const int c4 = lane + 64 * i;
       if (c4 < nv) {
         float4 o;
@@ -139,10 +148,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
         o.y = rs * (gd[i].y - m1 - xh[i].y * m2);
         o.z = rs * (gd[i].z - m1 - xh[i].z * m2);
         o.w = rs * (gd[i].w - m1 - xh[i].w * m2);
-        if (dres) {
-          const float4 r = *reinterpret_cast<const float4*>(dres + row * lddx + 4 * c4);
-          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-        }
+        if (dres) { o.x += rr[i].x; o.y += rr[i].y; o.z += rr[i].z; o.w += rr[i].w; }
         if (dx) *reinterpret_cast<float4*>(dx + row * lddx + 4 * c4) = o;
         if (dx_bf16) st4<bf16_t>(dx_bf16 + row * lddx + 4 * c4, o);
       }
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
   }
   if (want_w) {
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NVL; ++i) {
       const int c4 = lane + 64 * i;
       if (c4 < nv) {
         atomicAdd(dgamma + 4 * c4 + 0, ag[i].x); atomicAdd(dgamma + 4 * c4 + 1, ag[i].y);
@@ -197,14 +203,28 @@ extern "C" int mfnet_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, c
   if (dgamma && nblk > 512) nblk = 512;       // fewer waves -> fewer column atomics
   if (nblk > 65535 * 16) nblk = 65535 * 16;
   dim3 grid((unsigned)nblk), block(256);
-#define LN_BWD(TD, TX)                                                                                       \
-  hipLaunchKernelGGL((ln_bwd_kernel<TD, TX>), grid, block, 0, stream, (const TD*)dy, lddy, (const TX*)x, ldx, \
-                     mean, rstd, gamma, dres, dx, (bf16_t*)dx_bf16, lddx, dgamma, dbeta, rows, (int)C)
+#define LN_BWD_N(TD, TX, NVL)                                                                                      \
+  do {                                                                                                             \
+    if (dgamma)                                                                                                    \
+      hipLaunchKernelGGL((ln_bwd_kernel<TD, TX, NVL, true>), grid, block, 0, stream, (const TD*)dy, lddy, (const TX*)x, ldx, \
+                         mean, rstd, gamma, dres, dx, (bf16_t*)dx_bf16, lddx, dgamma, dbeta, rows, (int)C);        \
+    else                                                                                                           \
+      hipLaunchKernelGGL((ln_bwd_kernel<TD, TX, NVL, false>), grid, block, 0, stream, (const TD*)dy, lddy, (const TX*)x, ldx, \
+                         mean, rstd, gamma, dres, dx, (bf16_t*)dx_bf16, lddx, dgamma, dbeta, rows, (int)C);        \
+  } while (0)
+#define LN_BWD(TD, TX)                                                                                             \
+  do {                                                                                                             \
+    if (C <= 256) LN_BWD_N(TD, TX, 1);                                                                             \
+    else if (C <= 768) LN_BWD_N(TD, TX, 3);                                                                        \
+    else if (C <= 1280) LN_BWD_N(TD, TX, 5);                                                                       \
+    else LN_BWD_N(TD, TX, LN_MAXV);                                                                                \
+  } while (0)
   if (dy_dtype == MFNET_BF16 && x_dtype == MFNET_F32) LN_BWD(bf16_t, float);
   else if (dy_dtype == MFNET_F32 && x_dtype == MFNET_F32) LN_BWD(float, float);
   else if (dy_dtype == MFNET_BF16 && x_dtype == MFNET_BF16) LN_BWD(bf16_t, bf16_t);
   else if (dy_dtype == MFNET_F32 && x_dtype == MFNET_BF16) LN_BWD(float, bf16_t);
   else { mfnet_set_error("layernorm_bwd: bad dtype"); return MFNET_ERR_ARG; }
+#undef LN_BWD_N
 #undef LN_BWD
   MF_LAUNCH_CHECK("layernorm_bwd");
   return MFNET_OK;

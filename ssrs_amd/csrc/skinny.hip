@@ -35,18 +35,21 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(const bf16_t* __restrict
     }
     return wf.v;
   };
-  int s = wave;
-  for (; s + 12 < nsteps; s += 16) {          // four k-steps in flight per wave
-    const bf16x8_t x0 = *reinterpret_cast<const bf16x8_t*>(xp + 32 * s), x1 = *reinterpret_cast<const bf16x8_t*>(xp + 32 * (s + 4));
-    const bf16x8_t x2 = *reinterpret_cast<const bf16x8_t*>(xp + 32 * (s + 8)), x3 = *reinterpret_cast<const bf16x8_t*>(xp + 32 * (s + 12));
-    const bf16x8_t w0 = wfrag(s), w1 = wfrag(s + 4), w2 = wfrag(s + 8), w3 = wfrag(s + 12);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, x2, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3, x3, acc, 0, 0, 0);
+  // eight k-steps in flight per wave (a step past the end re-reads the last one and is not multiplied): K = 768 is
+  // one memory round trip per wave, K = 3072 three
+  for (int s = wave; s < nsteps; s += 32) {
+    bf16x8_t xv[8], wv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int si = min(s + 4 * i, nsteps - 1);
+      xv[i] = *reinterpret_cast<const bf16x8_t*>(xp + 32 * si);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wv[i] = wfrag(min(s + 4 * i, nsteps - 1));
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (s + 4 * i < nsteps) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[i], xv[i], acc, 0, 0, 0);
   }
-  for (; s < nsteps; s += 4)
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag(s), *reinterpret_cast<const bf16x8_t*>(xp + 32 * s), acc, 0, 0, 0);
   if (wave > 0) {
     red[wave - 1][lane][0] = acc[0]; red[wave - 1][lane][1] = acc[1]; red[wave - 1][lane][2] = acc[2]; red[wave - 1][lane][3] = acc[3];
   }

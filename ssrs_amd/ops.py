@@ -67,9 +67,17 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, want_f32=True, want_bf16=
     dxb = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
     if dres is not None:
         assert dres.is_contiguous() and dres.dtype == torch.float32
+    # weight gradients: one deterministic column reduction when the rows are dense (the dx kernel's own path adds
+    # them with float atomics from every wave)
+    split_w = (dgamma is not None and lddy == C and ldx == C and C % 4 == 0 and C <= 1024 and 256 % (C // 4) == 0
+               and dy2.is_contiguous() and x2.is_contiguous())
     call("mfnet_layernorm_bwd", dy2.data_ptr(), _DT[dy.dtype], lddy, x2.data_ptr(), _DT[x.dtype], ldx,
          mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), _p(dres), _p(dx), _p(dxb), C,
-         _p(dgamma), _p(dbeta), rows, C, _stream(x))
+         None if split_w else _p(dgamma), None if split_w else _p(dbeta), rows, C, _stream(x))
+    if split_w:
+        ws, tk = _colreduce_ws(1, rows, C, x.device)
+        call("mfnet_layernorm_bwd_weights", dy2.data_ptr(), _DT[dy.dtype], x2.data_ptr(), _DT[x.dtype], mean.data_ptr(), rstd.data_ptr(),
+             dgamma.data_ptr(), dbeta.data_ptr(), rows, C, ws.data_ptr(), tk.data_ptr(), _stream(x))
     return dx, dxb
 
 

@@ -24,7 +24,7 @@ def rnd(*shape, seed=0, scale=1.0):
 
 
 # ------------------------------------------------------------------------------------------ LayerNorm
-@pytest.mark.parametrize("rows,C", [(8192, 768), (1000, 256), (37, 128), (512, 1280)])
+@pytest.mark.parametrize("rows,C", [(8192, 768), (1000, 256), (37, 128), (512, 1280), (16384, 256), (4096, 64)])
 def test_layernorm_fwd_bwd(ops, rows, C):
     x = rnd(rows, C, seed=1, scale=3.0) + 0.5
     g = 1 + 0.1 * rnd(C, seed=2)
