@@ -264,7 +264,7 @@ int mfnet_gla_pool_bwd(const float* ds, float* d_o, int64_t B, int64_t H, int64_
  * fw = relu(w)/(relu(w0)+relu(w1)+eps) read from the device pointer w[2]; x [B,H/2,W/2,C] fp32. `perm`: row
  * order of skip = number of ConvTranspose(k2,s2) GEMMs stacked above the raster grid (0 raster, 1, 2), so no
  * pixel-shuffle pass exists. bwd: dx (fp32), dskip (skip's order), dw[2] += fusion-weight gradient; `sums` is a
- * 2-float scratch buffer supplied by the caller. */
+ * 64-float scratch buffer (32 slots x 2) supplied by the caller. */
 int mfnet_upfuse_fwd(const float* x, const void* skip, int skip_dtype, int perm, const float* w, float eps, void* out,
                      int out_dtype, int64_t B, int64_t H, int64_t W, int64_t C, hipStream_t stream);
 int mfnet_upfuse_bwd(const float* df, const float* x, const void* skip, int skip_dtype, int perm, const float* w, float eps,

@@ -884,7 +884,8 @@ __global__ __launch_bounds__(256) void upfuse_fwd_kernel(const float* __restrict
     st4(out, out_dt, i, f4add(f4scale(sk, f0), f4scale(up, f1)));
   }
 }
-// dskip[perm row] = fw0*df ; sums[0] += sum df*skip ; sums[1] += sum df*up(x)   (for the 2 fusion weights)
+#define UPFUSE_SLOTS 32
+// dskip[perm row] = fw0*df ; sums[slot][0] += sum df*skip ; sums[slot][1] += sum df*up(x)   (for the 2 fusion weights)
 __global__ __launch_bounds__(256) void upfuse_bwd_skip_kernel(const float* __restrict__ df, const float* __restrict__ x, const void* __restrict__ skip,
                                                               int skip_dt, int perm, const float* __restrict__ w, float eps,
                                                               void* __restrict__ dskip, int dskip_dt, float* __restrict__ sums,
@@ -915,8 +916,15 @@ __global__ __launch_bounds__(256) void upfuse_bwd_skip_kernel(const float* __res
     s0 += d.x * sk.x + d.y * sk.y + d.z * sk.z + d.w * sk.w;
     s1 += d.x * up.x + d.y * up.y + d.z * up.z + d.w * up.w;
   }
+  // float atomics on one address serialise (~25 ns each): one add per workgroup, spread over UPFUSE_SLOTS addresses
+  __shared__ float red[2][4];
   s0 = wave_sum(s0); s1 = wave_sum(s1);
-  if ((threadIdx.x & 63) == 0) { atomicAdd(sums, s0); atomicAdd(sums + 1, s1); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const float t = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    atomicAdd(sums + 2 * (blockIdx.x % UPFUSE_SLOTS) + threadIdx.x, t);
+  }
 }
 // generic adjoint of bilinear upsampling by integer factor s (gather form): dx[b,y,x,:] = fw * sum_{Y,X} wy(Y->y) wx(X->x) df[b,Y,X,:]
 __device__ __forceinline__ float bilin_wt(int O, int i, int n_in, float inv_scale) {
@@ -955,7 +963,9 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
 // d weights (2): fw = relu(w)/(S+eps), S = relu(w0)+relu(w1); sums = (dL/dfw0, dL/dfw1)
 __global__ void fuse_w_bwd_kernel(const float* w, float eps, const float* sums, float* dw) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const float a = fmaxf(w[0], 0.f), b = fmaxf(w[1], 0.f), S = a + b + eps, g0 = sums[0], g1 = sums[1];
+  float g0 = 0.f, g1 = 0.f;
+  for (int k = 0; k < UPFUSE_SLOTS; ++k) { g0 += sums[2 * k]; g1 += sums[2 * k + 1]; }
+  const float a = fmaxf(w[0], 0.f), b = fmaxf(w[1], 0.f), S = a + b + eps;
   const float common = (g0 * a + g1 * b) / (S * S);
   dw[0] += (w[0] > 0.f) ? (g0 / S - common) : 0.f;
   dw[1] += (w[1] > 0.f) ? (g1 / S - common) : 0.f;
@@ -970,12 +980,12 @@ extern "C" int mfnet_upfuse_fwd(const float* x, const void* skip, int skip_dtype
   return MFNET_OK;
 }
 // df [B,H,W,C] fp32 -> dx [B,H/2,W/2,C] fp32, dskip (skip's row order), dw[2] += gradient of the fusion weights.
-// sums: 2-float scratch owned by the caller (zeroed here).
+// sums: scratch of 64 floats (32 slots x 2) owned by the caller (zeroed here).
 extern "C" int mfnet_upfuse_bwd(const float* df, const float* x, const void* skip, int skip_dtype, int perm, const float* w, float eps,
                                 float* dx, void* dskip, int dskip_dtype, float* dw, float* sums, int64_t B, int64_t H, int64_t W, int64_t C,
                                 hipStream_t stream) {
   MF_CHECK_ARG(df && x && skip && w && dx && dskip && dw && sums && C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && perm >= 0 && perm <= 2, "upfuse_bwd: bad args");
-  hipError_t e = hipMemsetAsync(sums, 0, 2 * sizeof(float), stream);
+  hipError_t e = hipMemsetAsync(sums, 0, 2 * UPFUSE_SLOTS * sizeof(float), stream);
   if (e != hipSuccess) { mfnet_set_error("upfuse_bwd: memset: %s", hipGetErrorString(e)); return MFNET_ERR_HIP; }
   hipLaunchKernelGGL(upfuse_bwd_skip_kernel, dim3(grid_for(B * H * W * C / 4, 1024)), dim3(256), 0, stream, df, x, skip, skip_dtype, perm, w, eps, dskip,
                      dskip_dtype, sums, (int)B, (int)H, (int)W, (int)(C / 4));
@@ -1004,30 +1014,42 @@ __global__ __launch_bounds__(256) void up_final_fwd_kernel(const float* __restri
     out[i] = v;
   }
 }
-// dlogits [B,ncls,H,W] fp32 -> dx [B,h,w,ldx] bf16 (channels >= ncls are written as zero)
+// dlogits [B,ncls,H,W] fp32 -> dx [B,h,w,ldx] bf16 (channels >= ncls are written as zero). One thread per low-resolution
+// pixel: the adjoint of the xS bilinear upsample reads the <= (2S+2)^2 logit gradients whose interpolation touches the
+// pixel (exact weights from bilin_wt, separable: 2*(2S+2) weight evaluations), for every class, and writes the
+// pixel's whole channel row. (The first version ran one thread per (pixel, channel) of the 64-wide row - 6 of 64
+// lanes busy - over a (3.5S)^2 window: 147 us; the gradient map is 25 MB.)
+#define UPF_MAX_S 8
+#define UPF_MAX_CLS 16
 __global__ __launch_bounds__(256) void up_final_bwd_kernel(const float* __restrict__ dl, bf16_t* __restrict__ dx, int ldx, int B, int h, int wd, int ncls, int s) {
   const int H = h * s, W = wd * s;
   const float inv = 1.f / (float)s;
-  const int64_t total = (int64_t)B * h * wd * ldx;
-  GS_LOOP(i, total) {
-    const int c = (int)(i % ldx);
-    const int64_t pix = i / ldx;
-    if (c >= ncls) { dx[i] = 0; continue; }
+  const int64_t total = (int64_t)B * h * wd;
+  const int span = 2 * s + 2;
+  GS_LOOP(pix, total) {
     const int x = (int)(pix % wd), y = (int)((pix / wd) % h);
     const int64_t b = pix / ((int64_t)wd * h);
-    const float* db = dl + (b * ncls + c) * (int64_t)H * W;
-    float acc = 0.f;
-    const int Y0 = max(0, s * y - s - s / 2 - 1), Y1 = min(H - 1, s * y + 2 * s + s / 2);
-    const int X0 = max(0, s * x - s - s / 2 - 1), X1 = min(W - 1, s * x + 2 * s + s / 2);
-    for (int Y = Y0; Y <= Y1; ++Y) {
-      const float wy = bilin_wt(Y, y, h, inv);
-      if (wy == 0.f) continue;
-      for (int X = X0; X <= X1; ++X) {
-        const float wx = bilin_wt(X, x, wd, inv);
-        if (wx != 0.f) acc = fmaf(wy * wx, db[(int64_t)Y * W + X], acc);
+    const int Yb = s * y - s / 2 - 1 - (s & 1), Xb = s * x - s / 2 - 1 - (s & 1);
+    float wy[2 * UPF_MAX_S + 2], wx[2 * UPF_MAX_S + 2];
+    for (int k = 0; k < span; ++k) {
+      const int Y = Yb + k, X = Xb + k;
+      wy[k] = (Y >= 0 && Y < H) ? bilin_wt(Y, y, h, inv) : 0.f;
+      wx[k] = (X >= 0 && X < W) ? bilin_wt(X, x, wd, inv) : 0.f;
+    }
+    float acc[UPF_MAX_CLS];
+    for (int c = 0; c < ncls; ++c) acc[c] = 0.f;
+    for (int ky = 0; ky < span; ++ky) {
+      if (wy[ky] == 0.f) continue;
+      const int Y = Yb + ky;
+      for (int kx = 0; kx < span; ++kx) {
+        if (wx[kx] == 0.f) continue;
+        const float ww = wy[ky] * wx[kx];
+        const float* p = dl + (b * ncls * H + Y) * (int64_t)W + Xb + kx;
+        for (int c = 0; c < ncls; ++c) acc[c] = fmaf(ww, p[(int64_t)c * H * W], acc[c]);
       }
     }
-    dx[i] = f32_to_bf16(acc);
+    bf16_t* o = dx + pix * ldx;
+    for (int c = 0; c < ldx; ++c) o[c] = c < ncls ? f32_to_bf16(acc[c]) : (bf16_t)0;
   }
 }
 extern "C" int mfnet_up_final_fwd(const float* x, int64_t ldx, float* logits, int64_t B, int64_t h, int64_t w, int64_t ncls, int64_t s, hipStream_t stream) {
@@ -1037,8 +1059,8 @@ extern "C" int mfnet_up_final_fwd(const float* x, int64_t ldx, float* logits, in
   return MFNET_OK;
 }
 extern "C" int mfnet_up_final_bwd(const float* dlogits, void* dx, int64_t ldx, int64_t B, int64_t h, int64_t w, int64_t ncls, int64_t s, hipStream_t stream) {
-  MF_CHECK_ARG(dlogits && dx && ncls > 0 && ncls <= ldx && s >= 1 && s <= 8, "up_final_bwd: bad args");
-  hipLaunchKernelGGL(up_final_bwd_kernel, dim3(grid_for(B * h * w * ldx)), dim3(256), 0, stream, dlogits, (bf16_t*)dx, (int)ldx, (int)B, (int)h, (int)w, (int)ncls, (int)s);
+  MF_CHECK_ARG(dlogits && dx && ncls > 0 && ncls <= ldx && ncls <= UPF_MAX_CLS && s >= 1 && s <= UPF_MAX_S, "up_final_bwd: bad args (classes <= 16, scale <= 8)");
+  hipLaunchKernelGGL(up_final_bwd_kernel, dim3(grid_for(B * h * w)), dim3(256), 0, stream, dlogits, (bf16_t*)dx, (int)ldx, (int)B, (int)h, (int)w, (int)ncls, (int)s);
   MF_LAUNCH_CHECK("up_final_bwd");
   return MFNET_OK;
 }

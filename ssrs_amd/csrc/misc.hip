@@ -169,12 +169,13 @@ __global__ __launch_bounds__(256) void lora_mix_bwd_kernel(const float* __restri
     sx += pxx * ax - pxy * ay;
     sy += pyy * ay - pyx * ax;
   }
+  __shared__ float red[2][4];
   sx = wave_sum(sx);
   sy = wave_sum(sy);
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(dw, sx);
-    atomicAdd(dw + 1, sy);
-  }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sx; red[1][threadIdx.x >> 6] = sy; }
+  __syncthreads();
+  if (threadIdx.x < 2)     // one add per workgroup and scalar: same-address float atomics serialise
+    atomicAdd(dw + threadIdx.x, (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]));
 }
 extern "C" int mfnet_lora_mix_fwd(const float* a, const float* wx, const float* wy, float* U, int64_t M, int r, hipStream_t stream) {
   MF_CHECK_ARG(a && wx && wy && U && r > 0 && M % 2 == 0, "lora_mix_fwd: bad args");
@@ -189,7 +190,7 @@ extern "C" int mfnet_lora_mix_bwd(const float* P, const float* a, const float* w
   MF_CHECK_ARG(P && a && wx && wy && da && dw && r > 0 && M % 2 == 0, "lora_mix_bwd: bad args");
   if (M == 0) return MFNET_OK;
   unsigned g = grid_for(M / 2 * r);
-  if (g > 256) g = 256;
+  if (g > 128) g = 128;
   hipLaunchKernelGGL(lora_mix_bwd_kernel, dim3(g), dim3(256), 0, stream, P, a, wx, wy, da, dw, M / 2, r);
   MF_LAUNCH_CHECK("lora_mix_bwd");
   return MFNET_OK;

@@ -578,7 +578,7 @@ def upfuse_bwd(df, x, skip, perm, w, eps, B, H, W, dskip_dtype=torch.bfloat16):
     dx = torch.empty_like(x)
     dskip = torch.empty(skip.shape, dtype=dskip_dtype, device=x.device)
     dw = zeros(2, x.device)
-    sums = torch.empty(2, dtype=torch.float32, device=x.device)
+    sums = torch.empty(64, dtype=torch.float32, device=x.device)          # 32 slots x 2, zeroed by the entry point
     call("mfnet_upfuse_bwd", df.data_ptr(), x.data_ptr(), skip.data_ptr(), _dt(skip), perm, w.data_ptr(), float(eps), dx.data_ptr(),
          dskip.data_ptr(), _dt(dskip), dw.data_ptr(), sums.data_ptr(), B, H, W, C, _stream(x))
     return dx, dskip, dw
