@@ -78,7 +78,9 @@ int mfnet_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int6
  * [n_groups][R,K] (group stride w_group_stride elements; g(m) = (m / rows_per_group) % n_groups: the per-modality
  * LoRA matrices), R <= 16, K % 32 == 0, ldo % 4 == 0. tn: for each group z < n_groups, out_z[c,j] (or out_z[j,c]
  * if transposed) += scale * sum_{m < M} Y[z*M+m, c] U[z*M+m, j]; Y bf16, U fp32 [.,R], out_z = out +
- * z*out_group_stride (accumulates: zero `out` first). */
+ * z*out_group_stride (accumulates: zero `out` first). tn with out == NULL (a workspace is then required): only the
+ * partial tiles are produced, workspace[z][s][c][j] for s < splits = workspace_floats(M, C, R, n_groups) / (n_groups*C*R),
+ * unscaled; their sum is left to mfnet_gather_segments (red_n = splits). */
 int mfnet_skinny_nt(const void* X, int64_t ldx, const float* Wt, int64_t ldw, int64_t w_group_stride, int64_t rows_per_group,
                     int n_groups, float* out, int64_t ldo, int64_t M, int64_t K, int R, float scale, hipStream_t stream);
 int mfnet_skinny_tn(const void* Y, int64_t ldy, const float* U, int64_t ldu, float* out, int64_t M, int64_t C,
@@ -137,8 +139,11 @@ int mfnet_gemm_tn_bf16(const void* dy, int64_t ldy, const void* x, int64_t ldx, 
 int64_t mfnet_gemm_tn_splits(int64_t M, int64_t N, int64_t K);
 int mfnet_reduce_splits(const float* partial, float* out, int64_t n, int splits, float scale, int accumulate, hipStream_t stream);
 
-/* Strided gather of n small fp32 tensors in one launch (per 48 segments). desc is a HOST array of n x 14
- * int64: {src device ptr, dst device ptr, dims[4], src strides[4], dst strides[4]} with strides in elements;
+/* Strided gather of n small fp32 tensors in one launch (per 48 segments). desc is a HOST array of n x 17
+ * int64: {src device ptr, dst device ptr, dims[4], src strides[4], dst strides[4], red_n, red_stride, scale} with
+ * strides in elements and scale = the bits of a float in the low 32 bits; the value moved is
+ * scale * sum_{k < red_n} src[... + k*red_stride] (red_n = 1, scale = 1.0f: a plain copy), which folds the sum over the
+ * partial tiles of a split reduction (mfnet_skinny_tn with out == NULL, mfnet_gemm_tn_bf16) into the delivery;
  * dst_dtype MFNET_F32 (assign, or += when accumulate != 0) or MFNET_BF16 (assign). Replaces the framework
  * copies the reference's step performs implicitly: weight casts / permutes ahead of every conv and linear
  * (unetformer_mmsam.py:43-84 Conv/ConvBN/ConvTranspose modules, loralib/layers.py:149-165 B@A products) and

@@ -75,6 +75,10 @@ def weight_bf16(W2d: torch.Tensor, kind="w") -> torch.Tensor:
     return derived(key, tuple(W2d.shape), torch.bfloat16, lambda t: [(t, W2d)], device=W2d.device)
 
 
+def _real(g):
+    return g.materialize() if isinstance(g, ops.SplitSum) else g
+
+
 def deliver(params: Sequence[torch.Tensor], grads: Sequence) -> tuple:
     """-> the gradient tuple to return to autograd for `params`. grads[i] is None, a tensor view shaped like
     params[i] (any strides), or a list of (row_slice, tensor) pieces that tile params[i] along dim 0."""
@@ -89,14 +93,14 @@ def deliver(params: Sequence[torch.Tensor], grads: Sequence) -> tuple:
                 for sl, piece in g:
                     pairs.append((view[sl], piece))
             else:
-                pairs.append((view, g.view(p.shape) if g.shape != p.shape else g))
+                pairs.append((view, g.view(p.shape) if tuple(g.shape) != tuple(p.shape) else g))
             if notify is not None:
                 notes.append((notify, p))
             out.append(None)
         elif isinstance(g, list):
-            out.append(torch.cat([piece for _, piece in g], 0).view(p.shape))
+            out.append(torch.cat([_real(piece) for _, piece in g], 0).view(p.shape))
         else:
-            out.append(g.reshape(p.shape).contiguous())
+            out.append(_real(g).reshape(p.shape).contiguous())
     if pairs:
         ops.gather(pairs, accumulate=True)
         for notify, p in notes:

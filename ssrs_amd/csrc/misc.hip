@@ -1,6 +1,7 @@
 // Small HBM-bound data-movement kernels of the encoder path: dtype casts, patch-embed im2col,
 // 3x3 im2col / col2im for the neck conv, the LoRA cross-modal mix (loralib/layers.py:159-160).
 #include "common.h"
+#include <string.h>
 
 // ------------------------------------------------------------------------------------------- cast
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n8) {
@@ -253,7 +254,7 @@ extern "C" int mfnet_reduce_splits(const float* partial, float* out, int64_t n, 
 // module's backward to add the parameter gradients, in whatever layout the kernels produced them, into the
 // flat gradient buffer - instead of ~700 framework copy / cat / add launches per step.
 #define SEG_MAX 48
-struct GatherSeg { const float* src; void* dst; int dims[4]; int sstr[4]; int dstr[4]; };   // 64 bytes
+struct GatherSeg { const float* src; void* dst; int dims[4]; int sstr[4]; int dstr[4]; int red_n; int red_stride; float scale; int pad_; };   // 80 bytes
 struct GatherParams { GatherSeg seg[SEG_MAX]; };
 
 __global__ __launch_bounds__(256) void gather_segments_kernel(const GatherParams p, int mode) {
@@ -269,14 +270,31 @@ __global__ __launch_bounds__(256) void gather_segments_kernel(const GatherParams
     const unsigned i1 = u - i0 * d1;
     const int64_t so = (int64_t)i0 * s.sstr[0] + (int64_t)i1 * s.sstr[1] + (int64_t)i2 * s.sstr[2] + (int64_t)i3 * s.sstr[3];
     const int64_t dofs = (int64_t)i0 * s.dstr[0] + (int64_t)i1 * s.dstr[1] + (int64_t)i2 * s.dstr[2] + (int64_t)i3 * s.dstr[3];
-    const float v = s.src[so];
+    float v = s.src[so];
+    if (s.red_n > 1) {            // the source is a stack of red_n partial results (split reductions): summed here, in a
+      const float* q = s.src + so;   // fixed order, eight loads in flight
+      float a[8] = {v, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      int k = 1;
+      for (; k + 7 < s.red_n; k += 8) {
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = q[(int64_t)(k + e) * s.red_stride];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += t[e];
+      }
+      for (; k < s.red_n; ++k) a[0] += q[(int64_t)k * s.red_stride];
+      v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    v *= s.scale;
     if (mode == 2) ((bf16_t*)s.dst)[dofs] = f32_to_bf16(v);
     else if (mode == 1) ((float*)s.dst)[dofs] += v;
     else ((float*)s.dst)[dofs] = v;
   }
 }
 
-// desc: HOST array of n x 14 int64: {src ptr, dst ptr, dims[4], src strides[4], dst strides[4]} (strides in elements)
+// desc: HOST array of n x 17 int64: {src ptr, dst ptr, dims[4], src strides[4], dst strides[4], red_n, red_stride, scale}
+// (strides in elements; scale = the bits of a float in the low 32 bits). red_n > 1: the value copied / added is
+// scale * sum_{k < red_n} src[... + k*red_stride] - the partial tiles of a split reduction are summed on the way.
 extern "C" int mfnet_gather_segments(const int64_t* desc, int n, int dst_dtype, int accumulate, hipStream_t stream) {
   MF_CHECK_ARG(n >= 0 && (n == 0 || desc), "gather_segments: bad args");
   MF_CHECK_ARG(dst_dtype == MFNET_F32 || (dst_dtype == MFNET_BF16 && !accumulate), "gather_segments: accumulate needs an fp32 destination");
@@ -286,7 +304,7 @@ extern "C" int mfnet_gather_segments(const int64_t* desc, int n, int dst_dtype, 
     GatherParams p;
     int64_t nmax = 0;
     for (int i = 0; i < SEG_MAX; ++i) {
-      const int64_t* d = desc + (int64_t)(base + (i < cnt ? i : 0)) * 14;      // unused slots repeat a valid one
+      const int64_t* d = desc + (int64_t)(base + (i < cnt ? i : 0)) * 17;      // unused slots repeat a valid one
       GatherSeg& s = p.seg[i];
       s.src = (const float*)(uintptr_t)d[0]; s.dst = (void*)(uintptr_t)d[1];
       MF_CHECK_ARG(s.src && s.dst, "gather_segments: null pointer in segment %d", base + i);
@@ -298,10 +316,13 @@ extern "C" int mfnet_gather_segments(const int64_t* desc, int n, int dst_dtype, 
         tot *= d[2 + k];
       }
       MF_CHECK_ARG(tot < (1ll << 31), "gather_segments: segment %d too large", base + i);
-      if (i < cnt && tot > nmax) nmax = tot;
+      MF_CHECK_ARG(d[14] >= 1 && d[14] <= 4096 && d[15] >= 0 && d[15] < (1ll << 31), "gather_segments: bad reduction in segment %d", base + i);
+      s.red_n = (int)d[14]; s.red_stride = (int)d[15]; s.pad_ = 0;
+      { const unsigned int bits = (unsigned int)(d[16] & 0xffffffffll); memcpy(&s.scale, &bits, 4); }
+      if (i < cnt && tot * (d[14] < 16 ? d[14] : 16) > nmax) nmax = tot * (d[14] < 16 ? d[14] : 16);   // split sums: more, shorter threads
     }
     int64_t gx = ceil_div64(nmax, 256 * 8);
-    gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+    gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
     hipLaunchKernelGGL(gather_segments_kernel, dim3((unsigned)gx, (unsigned)cnt), dim3(256), 0, stream, p, mode);
     MF_LAUNCH_CHECK("gather_segments");
   }

@@ -289,7 +289,7 @@ extern "C" int mfnet_skinny_tn(const void* Y, int64_t ldy, const float* U, int64
                                int64_t M, int64_t C, int R, int transposed, float scale, int n_groups,
                                int64_t out_group_stride, float* workspace, int64_t workspace_floats, hipStream_t stream) {
   // M = rows PER GROUP; group z reads rows [z*M, (z+1)*M) and accumulates into out + z*out_group_stride
-  MF_CHECK_ARG(Y && U && out, "skinny_tn: null pointer");
+  MF_CHECK_ARG(Y && U && (out || workspace), "skinny_tn: null pointer (out may be NULL only with a workspace: partial tiles only)");
   MF_CHECK_ARG(C > 0 && C % 8 == 0 && ldy % 8 == 0 && ldy >= C, "skinny_tn: bad C/ldy");
   MF_CHECK_ARG(R == 4 || R == 8 || R == 16, "skinny_tn: R=%d must be 4, 8 or 16", R);
   MF_CHECK_ARG(ldu >= R && ldu % 4 == 0, "skinny_tn: bad ldu");
@@ -314,7 +314,7 @@ extern "C" int mfnet_skinny_tn(const void* Y, int64_t ldy, const float* U, int64
     if (R == 4) SKTN(4); else if (R == 8) SKTN(8); else SKTN(16);
 #undef SKTN
   }
-  if (partial) {
+  if (partial && out) {
     int64_t g = ceil_div64(C * R, 256);
     hipLaunchKernelGGL(skinny_tn_reduce_kernel, dim3((unsigned)g, (unsigned)n_groups), dim3(256), 0, stream, partial, out, (int)C, R, (int)splits, transposed, scale, out_group_stride);
   }

@@ -74,7 +74,7 @@ def _conv3_bwd(dy_bf, cols, w, B, H, W):
     """-> (dx fp32 [M, I], dW like w)."""
     dcols = ops.gemm(dy_bf, _wb_w3T(w))
     dx = ops.col2im3x3(dcols, B, H, W, w.shape[1])
-    return dx, _w3_grad(ops.gemm_tn(dy_bf, cols), w)
+    return dx, _w3_grad(ops.gemm_tn(dy_bf, cols, lazy=True), w)
 
 
 def _w2(w):          # 1x1 conv weight [O, I, 1, 1] -> [O, I]
@@ -205,12 +205,12 @@ class FpnFusionFn(torch.autograd.Function):
             # fpn2
             dY = dr[m][1].view(M3, 4 * C)
             ops.gemm(dY, _wb_ctT(f2[0].weight), residual=dd, out=dd)
-            _put(gd, f2[0].weight, _ct_grad(ops.gemm_tn(dY, dm), f2[0].weight))
+            _put(gd, f2[0].weight, _ct_grad(ops.gemm_tn(dY, dm, lazy=True), f2[0].weight))
             _put(gd, f2[0].bias, ops.bias_grad(dY.view(4 * M3, C)))
             # fpn1: second ConvT -> GELU -> norm -> first ConvT
             dY2 = dr[m][0].view(4 * M3, 4 * C)
             dn1 = ops.gemm(dY2, _wb_ctT(f1[3].weight), act=2, aux=s["n1"])
-            _put(gd, f1[3].weight, _ct_grad(ops.gemm_tn(dY2, s["a1"]), f1[3].weight))
+            _put(gd, f1[3].weight, _ct_grad(ops.gemm_tn(dY2, s["a1"], lazy=True), f1[3].weight))
             _put(gd, f1[3].bias, ops.bias_grad(dY2.view(16 * M3, C)))
             if m == "x":
                 ln = f1[1].ln
@@ -223,7 +223,7 @@ class FpnFusionFn(torch.autograd.Function):
                 _put(gd, f1[1].weight, dgam); _put(gd, f1[1].bias, dbet)
             dY1 = dt1.view(M3, 4 * C)
             ops.gemm(dY1, _wb_ctT(f1[0].weight), residual=dd, out=dd)
-            _put(gd, f1[0].weight, _ct_grad(ops.gemm_tn(dY1, dm), f1[0].weight))
+            _put(gd, f1[0].weight, _ct_grad(ops.gemm_tn(dY1, dm, lazy=True), f1[0].weight))
             _put(gd, f1[0].bias, ops.bias_grad(dY1.view(4 * M3, C)))
         return (ddeep.view(2 * B, h, w, C), None, None) + _grads(plist, gd)
 
@@ -250,7 +250,7 @@ class ConvBN1x1Fn(torch.autograd.Function):
         seq = ctx.seq
         dc, dg, dbt = _bn_bwd(dy.contiguous(), c, mean, rstd, seq[1], ctx.training, dx_dtype=BF)
         gd = {}
-        _put(gd, seq[0].weight, ops.gemm_tn(dc, x)); _put(gd, seq[1].weight, dg); _put(gd, seq[1].bias, dbt)
+        _put(gd, seq[0].weight, ops.gemm_tn(dc, x, lazy=True)); _put(gd, seq[1].weight, dg); _put(gd, seq[1].bias, dbt)
         dx = ops.gemm(dc, _wb(_w2(seq[0].weight).t()))
         return (dx, None, None) + _grads(ctx.plist, gd)
 
@@ -307,16 +307,16 @@ class BlockFn(torch.autograd.Function):
         d_bf = ops.cast(dout, BF)
         # ---- Mlp branch
         dhid = ops.gemm(d_bf, _wb(_w2(mlp.fc2.weight).t()), act=4, aux=hid)
-        _put(gd, mlp.fc2.weight, ops.gemm_tn(d_bf, hid)); _put(gd, mlp.fc2.bias, ops.bias_grad(d_bf))
+        _put(gd, mlp.fc2.weight, ops.gemm_tn(d_bf, hid, lazy=True)); _put(gd, mlp.fc2.bias, ops.bias_grad(d_bf))
         dn2 = ops.gemm(dhid, _wb(_w2(mlp.fc1.weight).t()))
-        _put(gd, mlp.fc1.weight, ops.gemm_tn(dhid, n2b)); _put(gd, mlp.fc1.bias, ops.bias_grad(dhid))
+        _put(gd, mlp.fc1.weight, ops.gemm_tn(dhid, n2b, lazy=True)); _put(gd, mlp.fc1.bias, ops.bias_grad(dhid))
         dx1b, dg, dbt = _bn_bwd(dn2, x1, m2, r2, blk.norm2, training)
         _put(gd, blk.norm2.weight, dg); _put(gd, blk.norm2.bias, dbt)
         dx1 = ops.add3(dout, dx1b)
         # ---- attention branch: x1 = x + proj1x1(BN(dw8x8(pool(o) + local)))
         dx1_bf = ops.cast(dx1, BF)
         dpb = ops.gemm(dx1_bf, _wb(_w2(a.proj[2].weight).t()))
-        _put(gd, a.proj[2].weight, ops.gemm_tn(dx1_bf, pb))
+        _put(gd, a.proj[2].weight, ops.gemm_tn(dx1_bf, pb, lazy=True))
         ddwo, dg, dbt = _bn_bwd(dpb, dwo, mp, rp, a.proj[1], training)
         _put(gd, a.proj[1].weight, dg); _put(gd, a.proj[1].bias, dbt)
         k = a.proj[0].weight.shape[-1]
@@ -334,7 +334,7 @@ class BlockFn(torch.autograd.Function):
         _put(gd, a.local1[0].weight, dW3)
         ops.gemm(dqkv, _wb(_w2(a.qkv[0].weight).t()), residual=dn1, out=dn1)
         ops.gemm(dc2, _wb(_w2(a.local2[0].weight).t()), residual=dn1, out=dn1)
-        _put(gd, a.qkv[0].weight, ops.gemm_tn(dqkv, n1b)); _put(gd, a.local2[0].weight, ops.gemm_tn(dc2, n1b))
+        _put(gd, a.qkv[0].weight, ops.gemm_tn(dqkv, n1b, lazy=True)); _put(gd, a.local2[0].weight, ops.gemm_tn(dc2, n1b, lazy=True))
         dxb, dg, dbt = _bn_bwd(dn1, x, m1, r1, blk.norm1, training)
         _put(gd, blk.norm1.weight, dg); _put(gd, blk.norm1.bias, dbt)
         dx = ops.add3(dx1, dxb)
@@ -365,7 +365,7 @@ def _fuse_bwd(dy, x, res, perm, m, geom, training, saved, gd):
     dx, dskip, dw = ops.upfuse_bwd(df, x, skip, perm, m.weights.detach(), m.eps, B, H, W)
     _put(gd, m.weights, dw)
     dres = ops.gemm(dskip, _wb(_w2(m.pre_conv[0].weight).t()))
-    _put(gd, m.pre_conv[0].weight, ops.gemm_tn(dskip, res))
+    _put(gd, m.pre_conv[0].weight, ops.gemm_tn(dskip, res, lazy=True))
     return dx, dres
 
 
@@ -426,7 +426,7 @@ class FRHFn(torch.autograd.Function):
         gd = {}
         dz = ops.act_bwd(dout.contiguous(), out, ACT_RELU6)                       # through the final ReLU6
         dpb = ops.gemm(dz, _wb(_w2(m.proj[2].weight).t()))
-        _put(gd, m.proj[2].weight, ops.gemm_tn(dz, pb))
+        _put(gd, m.proj[2].weight, ops.gemm_tn(dz, pb, lazy=True))
         ddw2, dg, dbt = _bn_bwd(dpb, dw2, mp, rp, m.proj[1], training)
         _put(gd, m.proj[1].weight, dg); _put(gd, m.proj[1].bias, dbt)
         dpc, dwp, _ = ops.dwconv_bwd(ddw2, pc, m.proj[0].weight.detach().reshape(-1, 9), B, H, W, 3, False)
@@ -439,7 +439,7 @@ class FRHFn(torch.autograd.Function):
         _put(gd, m.pa[0].weight, dwpa); _put(gd, m.pa[0].bias, dbpa)
         dcsc, dg, dbt = _bn_bwd(dz, csc, msc, rsc, m.shortcut[1], training, dx_dtype=BF)
         _put(gd, m.shortcut[1].weight, dg); _put(gd, m.shortcut[1].bias, dbt)
-        _put(gd, m.shortcut[0].weight, ops.gemm_tn(dcsc, xfb))
+        _put(gd, m.shortcut[0].weight, ops.gemm_tn(dcsc, xfb, lazy=True))
         dxf = ops.add3(dxf, dxf2)
         ops.gemm(dcsc, _wb(_w2(m.shortcut[0].weight).t()), residual=dxf, out=dxf)
         dx, dres = _fuse_bwd(dxf, x, res, ctx.perm, m, ctx.geom, training, saved, gd)
@@ -486,7 +486,7 @@ class SegHeadFn(torch.autograd.Function):
         w2c = _w2(head[2][0].weight)
         wpT = derived(("clsT", w2c.data_ptr()), (w2c.shape[1], NCLS_PAD), BF, lambda t: [(t[:, :ncls], w2c.t())], device=dlg.device)
         dhb = ops.gemm(dlg, wpT)
-        _put(gd, head[2][0].weight, ops.gemm_tn(dlg, hb)[:ncls])
+        _put(gd, head[2][0].weight, ops.gemm_tn(dlg, hb, lazy=True)[:ncls])
         dc, dg, dbt = _bn_bwd(dhb, c, mean, rstd, head[0][1], training, act=ACT_RELU6, dx_dtype=BF, chan_scale=drop_mask, rpi=H * W)
         _put(gd, head[0][1].weight, dg); _put(gd, head[0][1].bias, dbt)
         dx, dW3 = _conv3_bwd(dc, cols, head[0][0].weight, B, H, W)

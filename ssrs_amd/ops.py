@@ -181,19 +181,67 @@ def skinny_nt(x, wt, scale=1.0, out=None, rows_per_group=0):
     return out
 
 
-def skinny_tn(y, u, transposed: bool, scale=1.0, out=None, n_groups=1):
+class SplitSum:
+    """scale * sum over dim 0 of `part`, not taken yet: `bank.deliver` folds the sum into its gather launch (the
+    partial tiles of mfnet_skinny_tn / mfnet_gemm_tn_bf16), so weight gradients that go straight into the flat
+    gradient buffer need no reduce kernel of their own. Supports the view operations the backward passes apply to a
+    weight gradient (indexing, view, permute, t); `materialize()` gives the ordinary tensor."""
+
+    def __init__(self, part, scale=1.0):
+        self.part, self.scale = part, float(scale)
+
+    shape = property(lambda self: self.part.shape[1:])
+    device = property(lambda self: self.part.device)
+    dtype = property(lambda self: self.part.dtype)
+
+    def dim(self):
+        return self.part.dim() - 1
+
+    def __getitem__(self, idx):
+        idx = idx if isinstance(idx, tuple) else (idx,)
+        return SplitSum(self.part[(slice(None),) + idx], self.scale)
+
+    def view(self, *shape):
+        shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)) else shape
+        return SplitSum(self.part.view(self.part.shape[0], *shape), self.scale)
+
+    def permute(self, *dims):
+        dims = dims[0] if len(dims) == 1 and isinstance(dims[0], (tuple, list)) else dims
+        return SplitSum(self.part.permute(0, *[d + 1 for d in dims]), self.scale)
+
+    def t(self):
+        assert self.dim() == 2
+        return SplitSum(self.part.transpose(1, 2), self.scale)
+
+    def materialize(self):
+        out = torch.empty(tuple(self.shape), dtype=torch.float32, device=self.part.device)
+        gather([(out, self)])
+        return out
+
+
+def skinny_tn(y, u, transposed: bool, scale=1.0, out=None, n_groups=1, lazy=False):
     """per group z (rows [z*M/G, (z+1)*M/G)): out[z][c, j] (or [j, c] if transposed) += scale * sum_m y[m,c] u[m,j];
-    y bf16 [M,C], u fp32 [M,R]. Returns [G, C, R] / [G, R, C] (the leading dim is dropped for n_groups == 1)."""
+    y bf16 [M,C], u fp32 [M,R]. Returns [G, C, R] / [G, R, C] (the leading dim is dropped for n_groups == 1).
+    lazy: returns a SplitSum over the partial tiles instead (no reduce launch; for gradients handed to deliver)."""
     _chk(y, u, out)
     y2, M, C, ldy = _rows2d(y)
     R = u.shape[1]
     assert u.dtype == torch.float32 and u.stride(1) == 1 and u.shape[0] == M and M % n_groups == 0
-    if out is None:
-        out = zeros((n_groups, R, C) if transposed else (n_groups, C, R), y.device)
-    assert out.is_contiguous()
     Mg = M // n_groups
     nws = _lib.lib().mfnet_skinny_tn_workspace_floats(Mg, C, R, n_groups)
     ws = torch.empty(nws, dtype=torch.float32, device=y.device)
+    if lazy:
+        assert out is None
+        call("mfnet_skinny_tn", y2.data_ptr(), ldy, u.data_ptr(), u.stride(0), None, Mg, C, R,
+             1 if transposed else 0, float(scale), n_groups, C * R, ws.data_ptr(), nws, _stream(y))
+        part = ws.view(n_groups, nws // (n_groups * C * R), C, R).transpose(0, 1)          # [splits, G, C, R]
+        if transposed:
+            part = part.transpose(2, 3)
+        res = SplitSum(part, scale)
+        return res[0] if n_groups == 1 else res
+    if out is None:
+        out = zeros((n_groups, R, C) if transposed else (n_groups, C, R), y.device)
+    assert out.is_contiguous()
     call("mfnet_skinny_tn", y2.data_ptr(), ldy, u.data_ptr(), u.stride(0), out.data_ptr(), Mg, C, R,
          1 if transposed else 0, float(scale), n_groups, C * R, ws.data_ptr(), nws, _stream(y))
     return out[0] if (n_groups == 1 and out.dim() == 3) else out
@@ -387,10 +435,10 @@ def transpose_pad(x, mult=64):
     return y
 
 
-def gemm_tn(dy, x):
+def gemm_tn(dy, x, lazy=False):
     """dW[n,k] = sum_m dy[m,n] x[m,k]  (fp32 [N,K]); both bf16 row-major with M leading (views with a row
     stride are fine). The reduction runs over the rows (pixels / tokens): it is cut into splits whose partial
-    tiles one small kernel sums."""
+    tiles one small kernel sums - or, with lazy, the gradient delivery does (returns a SplitSum)."""
     _chk(dy, x)
     assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.stride(-1) == 1 and x.stride(-1) == 1
     d2, M, N, ldy = _rows2d(dy)
@@ -401,6 +449,8 @@ def gemm_tn(dy, x):
     call("mfnet_gemm_tn_bf16", d2.data_ptr(), ldy, x2.data_ptr(), ldx, M, N, K, part.data_ptr(), K, splits, _stream(dy))
     if splits == 1:
         return part[0]
+    if lazy:
+        return SplitSum(part)
     out = torch.empty((N, K), dtype=torch.float32, device=dy.device)
     call("mfnet_reduce_splits", part.data_ptr(), out.data_ptr(), out.numel(), splits, 1.0, 0, _stream(part))
     return out
@@ -852,10 +902,14 @@ def gather(pairs, accumulate=False):
     import ctypes
     if not pairs:
         return
+    import struct
     ddt = pairs[0][0].dtype
-    desc = (ctypes.c_int64 * (14 * len(pairs)))()
+    desc = (ctypes.c_int64 * (17 * len(pairs)))()
     k = 0
     for dst, src in pairs:
+        red_n, red_stride, scale = 1, 0, 1.0
+        if isinstance(src, SplitSum):
+            red_n, red_stride, scale, src = src.part.shape[0], src.part.stride(0), src.scale, src.part[0]
         _chk(dst, src)
         assert src.dtype == torch.float32 and dst.dtype == ddt and tuple(dst.shape) == tuple(src.shape), (dst.shape, src.shape)
         nd = dst.dim()
@@ -868,5 +922,7 @@ def gather(pairs, accumulate=False):
             desc[k + 2 + i] = dst.shape[j] if j >= 0 else 1
             desc[k + 6 + i] = src.stride(j) if j >= 0 else 0
             desc[k + 10 + i] = dst.stride(j) if j >= 0 else 0
-        k += 14
+        desc[k + 14], desc[k + 15] = red_n, red_stride
+        desc[k + 16] = struct.unpack("<I", struct.pack("<f", scale))[0]
+        k += 17
     call("mfnet_gather_segments", ctypes.cast(desc, ctypes.c_void_p), len(pairs), _DT[ddt], 1 if accumulate else 0, _stream(pairs[0][0]))

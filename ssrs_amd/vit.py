@@ -131,7 +131,7 @@ def _mix_V(lin, transposed=False):
 
 
 def _tn_groups(y_bf, u, half, transposed, scale=1.0):
-    o = ops.skinny_tn(y_bf, u, transposed, scale, n_groups=2)
+    o = ops.skinny_tn(y_bf, u, transposed, scale, n_groups=2, lazy=True)     # summed by the gradient delivery
     return o[0], o[1]
 
 
@@ -216,7 +216,7 @@ def _mix_linear_bwd(d_bf, x_bf, lin, saved, half, gelu_aux=None):
     r = a.shape[1]
     P = ops.skinny_nt(d_bf, _mix_V(lin, transposed=True))
     da, dw = ops.lora_mix_bwd(P, a, lin.lora_wx, lin.lora_wy)
-    dV = ops.skinny_tn(d_bf, U, False)
+    dV = ops.skinny_tn(d_bf, U, False, lazy=True)
     dAx, dAy = _tn_groups(x_bf, da, half, True)
     dx = ops.gemm(d_bf, wT_bf16(lin.weight), U=da, V=_stack2("A", lin.lora_Ax, lin.lora_Ay, transpose=True),
                   rows_per_group=half, n_groups=2, act=2 if gelu_aux is not None else 0, aux=gelu_aux)

@@ -54,7 +54,7 @@ def _dense_bwd(d_bf, x_bf, W, gelu_aux=None):
     """-> (dx bf16, dW fp32, db fp32) for y = x W^T + b."""
     wT = weight_bf16(W.t())
     dx = ops.gemm(d_bf, wT, act=2 if gelu_aux is not None else 0, aux=gelu_aux)
-    dW = ops.gemm_tn(d_bf, x_bf)
+    dW = ops.gemm_tn(d_bf, x_bf, lazy=True)          # summed over its splits by the gradient delivery
     db = ops.bias_grad(d_bf)
     return dx, dW, db
 

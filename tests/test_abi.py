@@ -42,7 +42,7 @@ def test_argument_errors_do_not_launch():
     assert rc == -1 and b"multiples of 8" in L.mfnet_last_error()
     assert L.mfnet_gemm_tn_splits(65536, 64, 576) >= 2 and L.mfnet_gemm_tn_splits(100, 64, 64) == 1
     # gather: a segment with a null pointer / an accumulate into bf16 is refused
-    desc = (ctypes.c_int64 * 14)(0, 16, 1, 1, 1, 4, 0, 0, 0, 1, 0, 0, 0, 1)
+    desc = (ctypes.c_int64 * 17)(0, 16, 1, 1, 1, 4, 0, 0, 0, 1, 0, 0, 0, 1, 1, 0, 0x3f800000)
     assert L.mfnet_gather_segments(ctypes.cast(desc, ctypes.c_void_p), 1, 0, 0, None) == -1 and b"null" in L.mfnet_last_error()
     assert L.mfnet_gather_segments(ctypes.cast(desc, ctypes.c_void_p), 1, 1, 1, None) == -1
     # deterministic column reductions need their workspace

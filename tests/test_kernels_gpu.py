@@ -339,6 +339,41 @@ def test_gather_segments(ops):
     assert torch.equal(db, mats[3].t().to(torch.bfloat16))
 
 
+def test_split_sums_are_folded_into_the_gather(ops):
+    """SplitSum sources: the partial tiles of the split weight-gradient reductions are summed (x scale) by the gather
+    launch that delivers them; lazy skinny_tn / gemm_tn results equal the eager ones bit for bit where the order is
+    the same, and through views / slices / transposes."""
+    part = rnd(5, 12, 20, seed=3)
+    ss = ops.SplitSum(part, 0.5)
+    d = torch.zeros(20, 12, device="cuda")
+    ops.gather([(d, ss.t())])
+    assert rel_err(d, 0.5 * part.sum(0).t()) < 1e-6
+    d2 = torch.ones(3, 4, 6, device="cuda")
+    ops.gather([(d2[:, :3], ss[3:6, :18].view(3, 3, 6))], accumulate=True)
+    ref2 = torch.ones(3, 4, 6, device="cuda")
+    ref2[:, :3] += 0.5 * part.sum(0)[3:6, :18].reshape(3, 3, 6)
+    assert rel_err(d2, ref2) < 1e-6
+    assert rel_err(ss.materialize(), 0.5 * part.sum(0)) < 1e-6
+    # lazy weight-gradient products
+    y = rnd(4096, 768, seed=4).to(torch.bfloat16)
+    u = rnd(4096, 8, seed=5)
+    for tr in (False, True):
+        e = ops.skinny_tn(y, u, tr, 0.25, n_groups=2)
+        lz = ops.skinny_tn(y, u, tr, 0.25, n_groups=2, lazy=True)
+        assert tuple(lz.shape) == tuple(e.shape)
+        assert rel_err(lz.materialize(), e) < 1e-6
+        assert rel_err(lz[1].materialize(), e[1]) < 1e-6
+    e1 = ops.skinny_tn(y, u, False)
+    l1 = ops.skinny_tn(y, u, False, lazy=True)
+    assert rel_err(l1[:, :4].materialize(), e1[:, :4]) < 1e-6
+    dy = rnd(65536, 64, seed=6).to(torch.bfloat16)
+    x = rnd(65536, 576, seed=7).to(torch.bfloat16)
+    e2 = ops.gemm_tn(dy, x)
+    l2 = ops.gemm_tn(dy, x, lazy=True)
+    assert isinstance(l2, ops.SplitSum) and rel_err(l2.materialize(), e2) < 1e-6
+    assert rel_err(l2.view(64, 3, 3, 64).permute(0, 3, 1, 2).materialize(), e2.view(64, 3, 3, 64).permute(0, 3, 1, 2)) < 1e-6
+
+
 # ------------------------------------------------------------------------------------------ column reductions
 @pytest.mark.parametrize("G,P,C,dt", [(1, 65536, 64, torch.float32), (1, 16384, 256, torch.bfloat16), (16, 4096, 64, torch.float32),
                                       (3, 777, 256, torch.float32), (1, 100, 1024, torch.float32), (2, 9, 8, torch.bfloat16)])
