@@ -11,11 +11,11 @@
 // out[m, j] = scale * sum_k X[m,k] * Wt[g(m)][j,k] on the matrix cores: the fp32 rank-R matrix is converted to
 // bf16 fragments in registers (rows >= R are zero), a block owns 16 rows of X and its 4 waves split K; the
 // accumulator tile is C[j][m], so each lane ends with 4 consecutive j of one row (one float4 store).
-__global__ __launch_bounds__(256) void skinny_nt_kernel(const bf16_t* __restrict__ X, int64_t ldx, const float* __restrict__ Wt,
+__global__ __launch_bounds__(1024) void skinny_nt_kernel(const bf16_t* __restrict__ X, int64_t ldx, const float* __restrict__ Wt,
                                                         int64_t ldw, int64_t w_group_stride, int64_t rows_per_group, int n_groups,
                                                         float* __restrict__ out, int64_t ldo, int64_t M, int K, int R, float scale) {
-  __shared__ float red[3][64][4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float red[15][64][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int64_t m0 = (int64_t)blockIdx.x * 16;
   const int g = n_groups > 1 ? (int)((m0 / rows_per_group) % n_groups) : 0;
@@ -35,28 +35,28 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(const bf16_t* __restrict
     }
     return wf.v;
   };
-  // eight k-steps in flight per wave (a step past the end re-reads the last one and is not multiplied): K = 768 is
-  // one memory round trip per wave, K = 3072 three
-  for (int s = wave; s < nsteps; s += 32) {
+  // The block's 4..16 waves split K so that each has at most eight k-steps, all in flight at once (a step past the end
+  // re-reads the last one and is not multiplied): one memory round trip per launch for K <= 4096.
+  // A wave takes PAIRS of adjacent k-steps (64 + 64 B = one 128-B line of each of its 16 rows, requested back to back).
+  for (int s = 0; s < nsteps; s += 8 * nw) {
     bf16x8_t xv[8], wv[8];
+    int si[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int si = min(s + 4 * i, nsteps - 1);
-      xv[i] = *reinterpret_cast<const bf16x8_t*>(xp + 32 * si);
-    }
+    for (int i = 0; i < 8; ++i) si[i] = s + 2 * (wave + nw * (i >> 1)) + (i & 1);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) wv[i] = wfrag(min(s + 4 * i, nsteps - 1));
+    for (int i = 0; i < 8; ++i) xv[i] = *reinterpret_cast<const bf16x8_t*>(xp + 32 * min(si[i], nsteps - 1));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wv[i] = wfrag(min(si[i], nsteps - 1));
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      if (s + 4 * i < nsteps) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[i], xv[i], acc, 0, 0, 0);
+      if (si[i] < nsteps) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[i], xv[i], acc, 0, 0, 0);
   }
   if (wave > 0) {
     red[wave - 1][lane][0] = acc[0]; red[wave - 1][lane][1] = acc[1]; red[wave - 1][lane][2] = acc[2]; red[wave - 1][lane][3] = acc[3];
   }
   __syncthreads();
   if (wave == 0 && m0 + fr < M) {
-#pragma unroll
-    for (int w = 0; w < 3; ++w) { acc[0] += red[w][lane][0]; acc[1] += red[w][lane][1]; acc[2] += red[w][lane][2]; acc[3] += red[w][lane][3]; }
+    for (int w = 0; w < nw - 1; ++w) { acc[0] += red[w][lane][0]; acc[1] += red[w][lane][1]; acc[2] += red[w][lane][2]; acc[3] += red[w][lane][3]; }
     float* op = out + (m0 + fr) * ldo + 4 * fq;      // j = 4*fq + r
     if (4 * fq + 3 < R) *reinterpret_cast<float4*>(op) = make_float4(acc[0] * scale, acc[1] * scale, acc[2] * scale, acc[3] * scale);
     else
@@ -276,7 +276,9 @@ extern "C" int mfnet_skinny_nt(const void* X, int64_t ldx, const float* Wt, int6
   MF_CHECK_ARG(n_groups >= 1 && (n_groups == 1 || (rows_per_group > 0 && rows_per_group % 16 == 0)), "skinny_nt: rows_per_group must be a multiple of 16");
   MF_CHECK_ARG(K < (1ll << 31), "skinny_nt: K too large");
   if (M <= 0) return MFNET_OK;
-  hipLaunchKernelGGL(skinny_nt_kernel, dim3((unsigned)ceil_div64(M, 16)), dim3(256), 0, stream, (const bf16_t*)X, ldx, Wt, ldw, w_group_stride,
+  int nw = (int)ceil_div64(K / 32, 8);
+  nw = nw < 4 ? 4 : (nw > 16 ? 16 : nw);
+  hipLaunchKernelGGL(skinny_nt_kernel, dim3((unsigned)ceil_div64(M, 16)), dim3(64 * nw), 0, stream, (const bf16_t*)X, ldx, Wt, ldw, w_group_stride,
                      rows_per_group, n_groups, out, ldo, M, (int)K, R, scale);
   MF_LAUNCH_CHECK("skinny_nt");
   return MFNET_OK;
