@@ -409,7 +409,7 @@ def adapter_mix_bwd(dh, ada, wx, wy):
 def bias_grad(dy, out=None):
     _chk(dy)
     dy2, M, N, ld = _rows2d(dy)
-    if out is None and ld == N and N % 4 == 0 and N <= 1024 and dy2.is_contiguous():
+    if out is None and ld == N and N % 4 == 0 and N <= 1024 and 256 % (N // 4) == 0 and dy2.is_contiguous():
         # the deterministic column reduction (16-byte loads for bf16), no float atomics
         return colsum(dy2, 1, M)[0].view(N)
     if out is None:

@@ -374,6 +374,16 @@ def test_split_sums_are_folded_into_the_gather(ops):
     assert rel_err(l2.view(64, 3, 3, 64).permute(0, 3, 1, 2).materialize(), e2.view(64, 3, 3, 64).permute(0, 3, 1, 2)) < 1e-6
 
 
+@pytest.mark.parametrize("M,N", [(4096, 768), (4096, 192), (16384, 256), (65536, 64), (1000, 3072), (77, 1280)])
+def test_bias_grad(ops, M, N):
+    """column sums of a bf16 gradient: widths that take the deterministic reduction (N/4 divides 256) and widths that take
+    the atomic kernel (768, 192, 3072, 1280 - the ViT adapters' and MLPs')."""
+    dy = rnd(M, N, seed=11).to(torch.bfloat16)
+    out = ops.bias_grad(dy)
+    assert tuple(out.shape) == (N,)
+    assert rel_err(out, dy.double().sum(0)) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------ column reductions
 @pytest.mark.parametrize("G,P,C,dt", [(1, 65536, 64, torch.float32), (1, 16384, 256, torch.bfloat16), (16, 4096, 64, torch.float32),
                                       (3, 777, 256, torch.float32), (1, 100, 1024, torch.float32), (2, 9, 8, torch.bfloat16)])

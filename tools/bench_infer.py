@@ -62,11 +62,27 @@ def main():
             eng.predict(img[:, :1024, :1024].contiguous(), dsm[:1024, :1024].contiguous(), 64)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run()
+        res = run()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        # the same job handed over in (pinned) host buffers: uint8 RGB + fp32 DSM in, uint8 mask out (never `value`)
+        rgb_h, dsm_h = rgb.cpu().pin_memory(), dsm.cpu().pin_memory()
+        mask_dev = res[1] if isinstance(res, tuple) else res
+        mask_h = torch.empty(mask_dev.shape, dtype=mask_dev.dtype).pin_memory()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        rgb2, dsm2 = rgb_h.to(dev, non_blocking=True), dsm_h.to(dev, non_blocking=True)
+        if kind.startswith("inference"):
+            r2 = eng.predict(rgb2, dsm2)
+            mask_h.copy_(r2[1], non_blocking=True)
+        else:
+            r2 = eng.predict(rgb2.float() / 255.0, dsm2, 64)
+            mask_h.copy_(r2, non_blocking=True)
+        torch.cuda.synchronize()
+        dt_pcie = time.perf_counter() - t1
         line = {"metric": "sliding-window inference window visits/sec", "grid": kind, "raster": f"{a.size}x{a.size}", "windows": n,
-                "value": round(n / dt, 1), "unit": "windows/s", "seconds_per_raster": round(dt, 3), "batch": a.batch,
+                "value": round(n / dt, 1), "unit": "windows/s", "seconds_per_raster": round(dt, 3),
+                "pcie_inclusive_windows_per_s": round(n / dt_pcie, 1), "pcie_inclusive_seconds": round(dt_pcie, 3), "batch": a.batch,
                 "model": f"{a.encoder} {a.mod}, {ncls} classes", "dtype": "bf16", "data": "synthetic"}
         print(json.dumps(line), flush=True)
         out.append(line)
