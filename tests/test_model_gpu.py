@@ -206,6 +206,26 @@ def test_vitb_eval_logits_vs_reference():
     _check_masks(out, g, tgt)
 
 
+@pytest.mark.parametrize("mod,encoder,tile,batch", [("sam_adpt", "vit_b", 256, 2), ("sam_lora", "vit_b", 256, 2), ("sam_lora", "vit_l", 512, 1)])
+def test_full_size_train_steps_run_and_learn(mod, encoder, tile, batch):
+    """SURVEY 8(d) configurations at their real widths (768 / 1024 channels, 192-wide adapters, a 32x32 token grid with
+    9 windows for ViT-L at 512 px) through the graph-captured engine: every kernel accepts its shapes, the loss is finite
+    and falls when the same batch is stepped on repeatedly."""
+    from ssrs_amd.trainer import TrainEngine
+    from ssrs_amd.unetformer_mmsam import UNetFormer
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = UNetFormer(num_classes=6, encoder=encoder, args=_args(mod))
+    m.load_state_dict(detfill.fill_state_dict(m.state_dict(), "full/"))
+    m = m.cuda().train()
+    rgb, dsm, tgt = [t.cuda() for t in detfill.tiles("full", batch, tile, 6)]
+    eng = TrainEngine(m, lr=0.01, momentum=0.9, weight_decay=5e-4, class_weight=torch.ones(6, device="cuda"), use_graph=True)
+    losses = [TrainEngine.read_metrics(eng.step(rgb, dsm, tgt))["loss"] for _ in range(6)]
+    assert all(np.isfinite(l) for l in losses), losses
+    assert losses[-1] < losses[0], losses
+    assert torch.isfinite(eng.flat_g).all() and eng.flat_g.abs().sum() > 0
+
+
 def test_cpu_tensors_are_rejected_loudly():
     from ssrs_amd._lib import MfnetError
     m = _tiny_model("sam_lora")
