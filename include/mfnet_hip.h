@@ -99,19 +99,21 @@ int mfnet_lora_mix_bwd(const float* P, const float* a, const float* wx, const fl
 
 /* ---- fused attention of the SAM blocks (lora_block.py:169-196 / adapter_fusionblock.py:176-198 with
  * add_decomposed_rel_pos :281-317, window_partition / window_unpartition :199-245).
- * qkv [G*Sh*Sw, 3*heads*hd] bf16 (q | k | v thirds, head-major), G = images x modalities, hd = 64.
+ * qkv [G*Sh*Sw, 3*heads*hd] bf16 (q | k | v thirds, head-major), G = images x modalities, hd = 64 (ViT-B / ViT-L) or
+ * 80 (ViT-H).
  * ws = 0: global attention over the Sh x Sw grid; ws > 0: ws x ws windows of the grid zero-padded at the
  * bottom/right; only real queries are computed, padded keys/values are synthesised from qkv_bias (their
  * input row is exactly zero after norm1), so nothing is inflated to the padded token count.
- * tbl [NT,64] bf16 = [rel_h resized to Lh = 2*KH-1 rows ; rel_w resized to Lw = 2*KW-1 rows ; zero rows],
+ * tbl [NT, hdp] bf16 = [rel_h resized to Lh = 2*KH-1 rows ; rel_w resized to Lw = 2*KW-1 rows ; zero rows], hdp = hd
+ * rounded up to a multiple of 32 with zero columns (64 -> 64, 80 -> 96),
  * NT % 32 == 0 (get_rel_pos' linear interpolation is done once on the host side, the tables are frozen);
  * scores = scale * q.k + q.rel_h[qh-kh+KH-1] + q.rel_w[qw-kw+KW-1] with the UNSCALED q in the bias terms.
  * Online softmax: no N x N tensor is materialised. out [G*Sh*Sw, heads*hd] bf16, lse [G,heads,Sh*Sw] fp32. */
 int mfnet_attn_fwd(const void* qkv, const float* qkv_bias, const void* tbl, void* out, float* lse, int64_t G,
                    int64_t Sh, int64_t Sw, int64_t heads, int64_t hd, int64_t ws, int64_t Lh, int64_t Lw,
                    int64_t NT, float scale, hipStream_t stream);
-/* dqkv [G*Sh*Sw, 3D] bf16 from dout; recomputes probabilities from lse. tblT [64,NT] bf16 = tbl^T.
- * NT <= 96 (token grids up to 24 x 24) in this version: larger grids return MFNET_ERR_UNSUPPORTED. */
+/* dqkv [G*Sh*Sw, 3D] bf16 from dout; recomputes probabilities from lse. tblT [hd,NT] bf16 = tbl[:, :hd]^T.
+ * Key grids up to KH + KW <= 128 (token grids up to 64 x 64). */
 int mfnet_attn_bwd(const void* qkv, const float* qkv_bias, const void* tbl, const void* tblT, const void* out,
                    const void* dout, const float* lse, void* dqkv, int64_t G, int64_t Sh, int64_t Sw,
                    int64_t heads, int64_t hd, int64_t ws, int64_t Lh, int64_t Lw, int64_t NT, float scale,

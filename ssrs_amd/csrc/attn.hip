@@ -22,13 +22,15 @@ struct AttnFwdParams {
   AttnGeom g;
   const bf16_t* qkv;      // [G*T, 3D]
   const float* qkv_bias;  // [3D] fp32 (padded keys / values)
-  const bf16_t* tbl;      // [NT, 64] bf16, rows >= Lh+Lw are zero
+  const bf16_t* tbl;      // [NT, 32*ceil(hd/32)] bf16, rows >= Lh+Lw and columns >= hd are zero
   bf16_t* out;            // [G*T, D]
   float* lse;             // [G, heads, T]
 };
 
-template <int NSG>      // 32-slot groups of the indicator product: ceil((KH + KW) / 32) rounded up to 1, 2 or 4
-__global__ __launch_bounds__(256, NSG == 1 ? 4 : 2) void attn_fwd_kernel(const AttnFwdParams p) {
+template <int NSG, int HD>      // NSG: 32-slot groups of the indicator product, ceil((KH + KW) / 32) rounded up to 1, 2 or 4
+__global__ __launch_bounds__(256, (NSG == 1 && HD <= 64) ? 4 : 2) void attn_fwd_kernel(const AttnFwdParams p) {
+  typedef AttHd<HD> H;
+  constexpr int KS = H::KS, UT = H::UT, ROWB = H::ROWB, CHS = H::CHS, CHV = H::CHV, RPI = H::RPI, NIT = ATT_KC / H::RPI;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const AttnGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -41,10 +43,10 @@ __global__ __launch_bounds__(256, NSG == 1 ? 4 : 2) void attn_fwd_kernel(const A
   const int Nk = g.KH * g.KW;
   const int TLD = g.NT + 4;
   const int nsg = (g.KH + g.KW + 31) >> 5;
-  const int regionA = att_region_a(g.NT);
+  const int regionA = att_region_a(g.NT, ROWB);
 
   unsigned char* K_lds = smem;                                     // [128][64] bf16, swizzled
-  unsigned char* V_lds = smem + ATT_KC * ATT_HD * 2;               // [128][64] bf16, swizzled
+  unsigned char* V_lds = smem + ATT_KC * ROWB;                     // [128][hd] bf16, swizzled
   float* T_lds = (float*)smem;                                     // [64][NT+4]: only until the key loop starts
   unsigned char* G_lds = smem + regionA;                           // [nsg][128][32] bf16 indicator rows
 
@@ -54,57 +56,52 @@ __global__ __launch_bounds__(256, NSG == 1 ? 4 : 2) void attn_fwd_kernel(const A
   // ---- this lane's query (column of every accumulator tile)
   const QueryPos qp = query_pos(g, wi, wj, qt0 + wave * 16 + fr);
   const bool wave_active = qt0 + wave * 16 < nq;                   // wave-uniform: waves without a query only stage
-  bf16x8_t qf[2];
-  {
-    const bf16_t* qptr = p.qkv + (row_base + qp.tok) * ld + head * ATT_HD + 8 * fq;
-    qf[0] = *reinterpret_cast<const bf16x8_t*>(qptr);
-    qf[1] = *reinterpret_cast<const bf16x8_t*>(qptr + 32);
-    if (!qp.valid) { qf[0] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}; qf[1] = qf[0]; }
-  }
+  bf16x8_t qf[KS];
+  att_load_row_frags<HD>(p.qkv + (row_base + qp.tok) * ld + head * HD, fq, qp.valid, qf);
   // this thread always stages 16-B chunk `ch` of a key row: the padded-key value of that chunk (the qkv bias,
   // rounded to bf16 like every other qkv entry) is kept in registers
-  const int ch = tid & 7;
-  const PaddedKV pad = att_padded_kv(p.qkv_bias, g.D, head, ch);
+  const int ch = tid % CHS, chl = ch < CHV ? ch : CHV - 1;         // slots >= CHV hold zeros (never loaded)
+  const PaddedKV pad = att_padded_kv(p.qkv_bias, g.D, head, HD, chl);
 
   // All global loads of a key chunk are issued first, unconditionally: padded / out-of-range keys read row 0
   // and are replaced when the registers are written to LDS. (Prefetching a chunk ahead costs 40 VGPRs, i.e.
   // one resident workgroup per CU, and measured 20 % slower.)
-  u32x4_t kv[ATT_KC / 32], vv[ATT_KC / 32];
-  int kkind[ATT_KC / 32];
+  u32x4_t kv[NIT], vv[NIT];
+  int kkind[NIT];
   auto issue_chunk = [&](int kc) {
 #pragma unroll
-    for (int it = 0; it < ATT_KC / 32; ++it) {
-      const int kg = kc + it * 32 + (tid >> 3);
+    for (int it = 0; it < NIT; ++it) {
+      const int kg = kc + it * RPI + tid / CHS;
       int kh = 0, kw = 0;
       const int tok = kg < Nk ? key_token(g, wi, wj, kg, &kh, &kw) : -2;
-      const bf16_t* src = p.qkv + (row_base + max(tok, 0)) * ld + g.D + head * ATT_HD + ch * 8;
+      const bf16_t* src = p.qkv + (row_base + max(tok, 0)) * ld + g.D + head * HD + chl * 8;
       kv[it] = *reinterpret_cast<const u32x4_t*>(src);
       vv[it] = *reinterpret_cast<const u32x4_t*>(src + g.D);
-      kkind[it] = tok < 0 ? (tok == -2 ? 2 : 1) : 0;               // 0 real, 1 padded, 2 beyond the window
+      kkind[it] = ch >= CHV ? 2 : (tok < 0 ? (tok == -2 ? 2 : 1) : 0);   // 0 real, 1 padded, 2 beyond the window / zero slot
     }
   };
   // ---- T^T = tbl . Q^T  -> T_lds[query][table row], then this lane's slots of T' / scale as bf16 hi + lo
   float* Trow = T_lds + (wave * 16 + fr) * TLD;
-  att_table_product(p.tbl, g.NT, qf, Trow, fr, fq);
+  att_table_product<HD>(p.tbl, g.NT, qf, Trow, fr, fq);
   bf16x8_t tqh[NSG], tql[NSG];
   att_slot_fragments<NSG>(g, Trow, qp.qh, qp.qw, fq, nsg, tqh, tql);
 
   float m_run = -INFINITY, l_run = 0.f;
   const float cs = g.scale * 1.4426950408889634f;                  // logits are scale * acc; exp via exp2
-  f32x4_t o[4];
+  f32x4_t o[UT];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) o[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < UT; ++u) o[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   for (int kc = 0; kc < Nk; kc += ATT_KC) {
     issue_chunk(kc);
     __syncthreads();   // previous chunk fully consumed (first pass: every wave has read its T rows)
 #pragma unroll
-    for (int it = 0; it < ATT_KC / 32; ++it) {
-      const int kl = it * 32 + (tid >> 3);
+    for (int it = 0; it < NIT; ++it) {
+      const int kl = it * RPI + tid / CHS;
       u32x4_t k4 = kkind[it] == 0 ? kv[it] : pad.k, v4 = kkind[it] == 0 ? vv[it] : pad.v;
       if (kkind[it] == 2) { k4 = (u32x4_t){0u, 0u, 0u, 0u}; v4 = k4; }
-      *reinterpret_cast<u32x4_t*>(K_lds + kl * 128 + ((ch ^ kswz(kl)) << 4)) = k4;
-      *reinterpret_cast<u32x4_t*>(V_lds + kl * 128 + ((ch ^ kswz(kl)) << 4)) = v4;
+      *reinterpret_cast<u32x4_t*>(K_lds + kl * ROWB + ((ch ^ kswz(kl)) << 4)) = k4;
+      *reinterpret_cast<u32x4_t*>(V_lds + kl * ROWB + ((ch ^ kswz(kl)) << 4)) = v4;
     }
     att_stage_indicator(g, G_lds, kc, Nk, nsg, tid);
     __syncthreads();
@@ -118,8 +115,8 @@ __global__ __launch_bounds__(256, NSG == 1 ? 4 : 2) void attn_fwd_kernel(const A
           s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
           const int kr = kt * 64 + 16 * t + fr;
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(K_lds + kr * 128 + (((fq + 4 * ks) ^ kswz(kr)) << 4));
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(K_lds + kr * ROWB + (((fq + 4 * ks) ^ kswz(kr)) << 4));
             s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
           }
 #pragma unroll
@@ -158,7 +155,7 @@ __global__ __launch_bounds__(256, NSG == 1 ? 4 : 2) void attn_fwd_kernel(const A
           }
         l_run = l_run * alpha + psum;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { o[u][0] *= alpha; o[u][1] *= alpha; o[u][2] *= alpha; o[u][3] *= alpha; }
+        for (int u = 0; u < UT; ++u) { o[u][0] *= alpha; o[u][1] *= alpha; o[u][2] *= alpha; o[u][3] *= alpha; }
         // ---- O^T += V^T . P^T ; element j of k-step s2 <-> key 32*s2 + 16*(j>>2) + 4*fq + (j&3). The V^T
         // fragment comes from two transposing reads of 4 keys x 16 head-dims each (lane 4q+p of a 16-lane
         // group addresses key q, head-dims 4p..4p+3 of the block; lane i receives head-dim i of the 4 keys).
@@ -171,11 +168,11 @@ __global__ __launch_bounds__(256, NSG == 1 ? 4 : 2) void attn_fwd_kernel(const A
           pf.w[3] = pack_bf16x2(s[2 * s2 + 1][2], s[2 * s2 + 1][3]);
           const int vrow = kt * 64 + 32 * s2 + 4 * fq + (fr >> 2);
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const unsigned char* va = V_lds + vrow * 128 + (((2 * u + ((fr >> 1) & 1)) ^ kswz(vrow)) << 4) + ((fr & 1) << 3);
+          for (int u = 0; u < UT; ++u) {
+            const unsigned char* va = V_lds + vrow * ROWB + (((2 * u + ((fr >> 1) & 1)) ^ kswz(vrow)) << 4) + ((fr & 1) << 3);
             union { bf16x8_t v; s16x4_t h[2]; } vf;
             vf.h[0] = att_tr_read(va);
-            vf.h[1] = att_tr_read(va + 16 * 128);
+            vf.h[1] = att_tr_read(va + 16 * ROWB);
             o[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[u], 0, 0, 0);
           }
         }
@@ -187,9 +184,9 @@ __global__ __launch_bounds__(256, NSG == 1 ? 4 : 2) void attn_fwd_kernel(const A
   l_run += __shfl_xor(l_run, 32, 64);
   if (qp.valid) {
     const float inv = 1.f / l_run;
-    bf16_t* op = p.out + (row_base + qp.tok) * g.D + head * ATT_HD + 4 * fq;
+    bf16_t* op = p.out + (row_base + qp.tok) * g.D + head * HD + 4 * fq;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UT; ++u) {
       u32x2_t w;
       w.x = pack_bf16x2(o[u][0] * inv, o[u][1] * inv);
       w.y = pack_bf16x2(o[u][2] * inv, o[u][3] * inv);
@@ -201,7 +198,7 @@ __global__ __launch_bounds__(256, NSG == 1 ? 4 : 2) void attn_fwd_kernel(const A
 
 int attn_fill_geom(AttnGeom* g, int64_t G, int64_t Sh, int64_t Sw, int64_t heads, int64_t hd, int64_t ws,
                    int64_t Lh, int64_t Lw, int64_t NT, float scale, const char* who) {
-  MF_CHECK_ARG(hd == ATT_HD, "%s: head dim %lld unsupported (only 64)", who, (long long)hd);
+  MF_CHECK_ARG(hd == 64 || hd == 80, "%s: head dim %lld unsupported (64: ViT-B / ViT-L, 80: ViT-H)", who, (long long)hd);
   MF_CHECK_ARG(G > 0 && Sh > 0 && Sw > 0 && heads > 0 && ws >= 0, "%s: bad geometry", who);
   g->G = (int)G; g->Sh = (int)Sh; g->Sw = (int)Sw; g->heads = (int)heads; g->D = (int)(heads * hd);
   g->ws = (int)ws;
@@ -216,8 +213,8 @@ int attn_fill_geom(AttnGeom* g, int64_t G, int64_t Sh, int64_t Sw, int64_t heads
   return MFNET_OK;
 }
 
-static size_t attn_fwd_lds(const AttnGeom& g) {
-  return (size_t)att_region_a(g.NT) + (size_t)((g.KH + g.KW + 31) / 32) * ATT_KC * ATT_GROW;
+static size_t attn_fwd_lds(const AttnGeom& g, int rowb) {
+  return (size_t)att_region_a(g.NT, rowb) + (size_t)((g.KH + g.KW + 31) / 32) * ATT_KC * ATT_GROW;
 }
 
 // number of (window, 64-query tile) pairs of one image = grid.x of the query-tiled kernels
@@ -240,13 +237,16 @@ extern "C" int mfnet_attn_fwd(const void* qkv, const float* qkv_bias, const void
   int rc = attn_fill_geom(&p.g, G, Sh, Sw, heads, hd, ws, Lh, Lw, NT, scale, "attn_fwd");
   if (rc) return rc;
   p.qkv = (const bf16_t*)qkv; p.qkv_bias = qkv_bias; p.tbl = (const bf16_t*)tbl; p.out = (bf16_t*)out; p.lse = lse;
-  const size_t lds = attn_fwd_lds(p.g);
+  const int rowb = hd <= 64 ? AttHd<64>::ROWB : AttHd<80>::ROWB;
+  const size_t lds = attn_fwd_lds(p.g, rowb);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) { mfnet_set_error("attn_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MFNET_ERR_HIP; }
+    const void* fns[6] = {(const void*)attn_fwd_kernel<1, 64>, (const void*)attn_fwd_kernel<2, 64>, (const void*)attn_fwd_kernel<4, 64>,
+                          (const void*)attn_fwd_kernel<1, 80>, (const void*)attn_fwd_kernel<2, 80>, (const void*)attn_fwd_kernel<4, 80>};
+    for (int i = 0; i < 6; ++i) {
+      hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) { mfnet_set_error("attn_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MFNET_ERR_HIP; }
+    }
     attr_set = true;
   }
   MF_CHECK_ARG(p.g.KH + p.g.KW <= 128, "attn_fwd: key grid %dx%d too large (KH + KW <= 128)", p.g.KH, p.g.KW);
@@ -254,9 +254,14 @@ extern "C" int mfnet_attn_fwd(const void* qkv, const float* qkv_bias, const void
   MF_CHECK_ARG(grid.z <= 65535 && grid.y <= 65535, "attn_fwd: grid too large");
   MF_CHECK_ARG(lds <= 160 * 1024, "attn_fwd: LDS demand too large");
   const int nsg = (p.g.KH + p.g.KW + 31) / 32;
-  if (nsg <= 1) hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, dim3(256), lds, stream, p);
-  else if (nsg == 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(256), lds, stream, p);
-  else hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(256), lds, stream, p);
+#define ATT_FWD(HDV)                                                                                   \
+  do {                                                                                                 \
+    if (nsg <= 1) hipLaunchKernelGGL((attn_fwd_kernel<1, HDV>), grid, dim3(256), lds, stream, p);      \
+    else if (nsg == 2) hipLaunchKernelGGL((attn_fwd_kernel<2, HDV>), grid, dim3(256), lds, stream, p); \
+    else hipLaunchKernelGGL((attn_fwd_kernel<4, HDV>), grid, dim3(256), lds, stream, p);               \
+  } while (0)
+  if (hd == 64) ATT_FWD(64); else ATT_FWD(80);
+#undef ATT_FWD
   MF_LAUNCH_CHECK("attn_fwd");
   return MFNET_OK;
 }

@@ -19,8 +19,8 @@ struct AttnBwdParams {
   AttnGeom g;
   const bf16_t* qkv;      // [G*T, 3D]
   const float* qkv_bias;  // [3D]
-  const bf16_t* tbl;      // [NT, 64]
-  const bf16_t* tblT;     // [64, NT]
+  const bf16_t* tbl;      // [NT, 32*ceil(hd/32)], zero padded columns
+  const bf16_t* tblT;     // [hd, NT]
   const bf16_t* out;      // [G*T, D] forward output O
   const bf16_t* dout;     // [G*T, D]
   const float* lse;       // [G, heads, T]
@@ -31,8 +31,10 @@ struct AttnBwdParams {
 // Same structure as attn_fwd_kernel (attn.hip): compact (window, tile) grid, K / V row-major in LDS, rel-pos
 // bias as the indicator product G.T'^T. The two transposed operands of this kernel, K^T (dQ^T += K^T.dS^T) and
 // G^T (dT'^T += G^T.dS^T), are read from the SAME row-major images with ds_read_b64_tr_b16.
-template <int NSG>
-__global__ __launch_bounds__(256, NSG == 1 ? 3 : (NSG == 2 ? 2 : 1)) void attn_bwd_dq_kernel(const AttnBwdParams p) {
+template <int NSG, int HD>
+__global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : (NSG == 2 ? 2 : 1))) void attn_bwd_dq_kernel(const AttnBwdParams p) {
+  typedef AttHd<HD> H;
+  constexpr int KS = H::KS, UT = H::UT, ROWB = H::ROWB, CHS = H::CHS, CHV = H::CHV, RPI = H::RPI, NIT = ATT_KC / H::RPI;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const AttnGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -47,76 +49,68 @@ __global__ __launch_bounds__(256, NSG == 1 ? 3 : (NSG == 2 ? 2 : 1)) void attn_b
   const int nsg = (g.KH + g.KW + 31) >> 5;
 
   unsigned char* K_lds = smem;                                        // [128][64] swizzled
-  unsigned char* V_lds = smem + ATT_KC * ATT_HD * 2;                  // [128][64] swizzled
+  unsigned char* V_lds = smem + ATT_KC * ROWB;                        // [128][hd] swizzled
   float* T_lds = (float*)smem;                                        // [64][NT+4] before the key loop; dT after it
-  unsigned char* G_lds = smem + att_region_a(g.NT);                   // [nsg][128][32] bf16 indicator rows
+  unsigned char* G_lds = smem + att_region_a(g.NT, ROWB);             // [nsg][128][32] bf16 indicator rows
 
   const int64_t row_base = (int64_t)gi * T;
   const int64_t ld = 3 * (int64_t)g.D;
   const QueryPos qp = query_pos(g, wi, wj, qt0 + wave * 16 + fr);
   const bool wave_active = qt0 + wave * 16 < nq;
 
-  bf16x8_t qf[2], dof[2];
+  bf16x8_t qf[KS], dof[KS];
   float delta = 0.f, lse2 = 0.f;
   {
-    const bf16x8_t z = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
-    const bf16_t* qptr = p.qkv + (row_base + qp.tok) * ld + head * ATT_HD + 8 * fq;
-    const bf16_t* dptr = p.dout + (row_base + qp.tok) * g.D + head * ATT_HD + 8 * fq;
-    const bf16_t* optr = p.out + (row_base + qp.tok) * g.D + head * ATT_HD + 8 * fq;
-    qf[0] = *reinterpret_cast<const bf16x8_t*>(qptr);
-    qf[1] = *reinterpret_cast<const bf16x8_t*>(qptr + 32);
-    dof[0] = *reinterpret_cast<const bf16x8_t*>(dptr);
-    dof[1] = *reinterpret_cast<const bf16x8_t*>(dptr + 32);
-    const bf16x8_t o0 = *reinterpret_cast<const bf16x8_t*>(optr);
-    const bf16x8_t o1 = *reinterpret_cast<const bf16x8_t*>(optr + 32);
-    lse2 = p.lse[((int64_t)gi * g.heads + head) * T + qp.tok] * 1.4426950408889634f;
+    bf16x8_t of[KS];
+    att_load_row_frags<HD>(p.qkv + (row_base + qp.tok) * ld + head * HD, fq, qp.valid, qf);
+    att_load_row_frags<HD>(p.dout + (row_base + qp.tok) * g.D + head * HD, fq, qp.valid, dof);
+    att_load_row_frags<HD>(p.out + (row_base + qp.tok) * g.D + head * HD, fq, qp.valid, of);
+    lse2 = qp.valid ? p.lse[((int64_t)gi * g.heads + head) * T + qp.tok] * 1.4426950408889634f : 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      delta += bf16_to_f32((bf16_t)dof[0][e]) * bf16_to_f32((bf16_t)o0[e]);
-      delta += bf16_to_f32((bf16_t)dof[1][e]) * bf16_to_f32((bf16_t)o1[e]);
-    }
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) delta += bf16_to_f32((bf16_t)dof[ks][e]) * bf16_to_f32((bf16_t)of[ks][e]);
     delta += __shfl_xor(delta, 16, 64);
     delta += __shfl_xor(delta, 32, 64);
-    if (!qp.valid) { qf[0] = qf[1] = dof[0] = dof[1] = z; delta = 0.f; lse2 = 0.f; }
   }
   // T^T = tbl . Q^T -> T_lds, then this lane's slots of T' / scale (attn.hip)
   float* Trow = T_lds + (wave * 16 + fr) * TLD;
-  att_table_product(p.tbl, g.NT, qf, Trow, fr, fq);
+  att_table_product<HD>(p.tbl, g.NT, qf, Trow, fr, fq);
   bf16x8_t tqh[NSG], tql[NSG];
   att_slot_fragments<NSG>(g, Trow, qp.qh, qp.qw, fq, nsg, tqh, tql);
   const float cs = g.scale * 1.4426950408889634f;
 
-  f32x4_t dq[4], dgt[NSG][2];
+  f32x4_t dq[UT], dgt[NSG][2];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) dq[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < UT; ++u) dq[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int c = 0; c < NSG; ++c) dgt[c][0] = dgt[c][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  const int ch = tid & 7;          // this thread always stages 16-B chunk `ch` of a key row
-  const PaddedKV pad = att_padded_kv(p.qkv_bias, g.D, head, ch);
+  const int ch = tid % CHS, chl = ch < CHV ? ch : CHV - 1;   // this thread always stages 16-B chunk slot `ch` of a key row
+  const PaddedKV pad = att_padded_kv(p.qkv_bias, g.D, head, HD, chl);
 
   for (int kc = 0; kc < Nk; kc += ATT_KC) {
     // all global loads of the chunk first, unconditionally (see attn_fwd_kernel)
-    u32x4_t kv[ATT_KC / 32], vv[ATT_KC / 32];
-    int kkind[ATT_KC / 32];
+    u32x4_t kv[NIT], vv[NIT];
+    int kkind[NIT];
 #pragma unroll
-    for (int it = 0; it < ATT_KC / 32; ++it) {
-      const int kg = kc + it * 32 + (tid >> 3);
+    for (int it = 0; it < NIT; ++it) {
+      const int kg = kc + it * RPI + tid / CHS;
       int kh = 0, kw = 0;
       const int tok = kg < Nk ? key_token(g, wi, wj, kg, &kh, &kw) : -2;
-      const bf16_t* src = p.qkv + (row_base + max(tok, 0)) * ld + g.D + head * ATT_HD + ch * 8;
+      const bf16_t* src = p.qkv + (row_base + max(tok, 0)) * ld + g.D + head * HD + chl * 8;
       kv[it] = *reinterpret_cast<const u32x4_t*>(src);
       vv[it] = *reinterpret_cast<const u32x4_t*>(src + g.D);
-      kkind[it] = tok < 0 ? (tok == -2 ? 2 : 1) : 0;
+      kkind[it] = ch >= CHV ? 2 : (tok < 0 ? (tok == -2 ? 2 : 1) : 0);
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < ATT_KC / 32; ++it) {
-      const int kl = it * 32 + (tid >> 3);
+    for (int it = 0; it < NIT; ++it) {
+      const int kl = it * RPI + tid / CHS;
       u32x4_t k4 = kkind[it] == 0 ? kv[it] : pad.k, v4 = kkind[it] == 0 ? vv[it] : pad.v;
       if (kkind[it] == 2) { k4 = (u32x4_t){0u, 0u, 0u, 0u}; v4 = k4; }
-      *reinterpret_cast<u32x4_t*>(K_lds + kl * 128 + ((ch ^ kswz(kl)) << 4)) = k4;
-      *reinterpret_cast<u32x4_t*>(V_lds + kl * 128 + ((ch ^ kswz(kl)) << 4)) = v4;
+      *reinterpret_cast<u32x4_t*>(K_lds + kl * ROWB + ((ch ^ kswz(kl)) << 4)) = k4;
+      *reinterpret_cast<u32x4_t*>(V_lds + kl * ROWB + ((ch ^ kswz(kl)) << 4)) = v4;
     }
     att_stage_indicator(g, G_lds, kc, Nk, nsg, tid);
     __syncthreads();
@@ -130,8 +124,8 @@ __global__ __launch_bounds__(256, NSG == 1 ? 3 : (NSG == 2 ? 2 : 1)) void attn_b
           dp[t] = s[t];
           const int kr = kt * 64 + 16 * t + fr;
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            const int off = kr * 128 + (((fq + 4 * ks) ^ kswz(kr)) << 4);
+          for (int ks = 0; ks < KS; ++ks) {
+            const int off = kr * ROWB + (((fq + 4 * ks) ^ kswz(kr)) << 4);
             s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(K_lds + off), qf[ks], s[t], 0, 0, 0);
             dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(V_lds + off), dof[ks], dp[t], 0, 0, 0);
           }
@@ -164,11 +158,11 @@ __global__ __launch_bounds__(256, NSG == 1 ? 3 : (NSG == 2 ? 2 : 1)) void attn_b
           pf.w[3] = pack_bf16x2(s[2 * s2 + 1][2], s[2 * s2 + 1][3]);
           const int krow = kt * 64 + 32 * s2 + 4 * fq + (fr >> 2);
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const unsigned char* ka = K_lds + krow * 128 + (((2 * u + ((fr >> 1) & 1)) ^ kswz(krow)) << 4) + ((fr & 1) << 3);
+          for (int u = 0; u < UT; ++u) {
+            const unsigned char* ka = K_lds + krow * ROWB + (((2 * u + ((fr >> 1) & 1)) ^ kswz(krow)) << 4) + ((fr & 1) << 3);
             union { bf16x8_t v; s16x4_t h[2]; } kf;
             kf.h[0] = att_tr_read(ka);
-            kf.h[1] = att_tr_read(ka + 16 * 128);
+            kf.h[1] = att_tr_read(ka + 16 * ROWB);
             dq[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf.v, pf.v, dq[u], 0, 0, 0);
           }
 #pragma unroll
@@ -191,7 +185,7 @@ __global__ __launch_bounds__(256, NSG == 1 ? 3 : (NSG == 2 ? 2 : 1)) void attn_b
   __syncthreads();   // K / V images dead: their LDS becomes dT
   float* dTrow = T_lds + (wave * 16 + fr) * TLD;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) { dq[u][0] *= g.scale; dq[u][1] *= g.scale; dq[u][2] *= g.scale; dq[u][3] *= g.scale; }
+  for (int u = 0; u < UT; ++u) { dq[u][0] *= g.scale; dq[u][1] *= g.scale; dq[u][2] *= g.scale; dq[u][3] *= g.scale; }
   for (int t = 0; t < g.NT / 16; ++t) *reinterpret_cast<float4*>(dTrow + 16 * t + 4 * fq) = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   // dT[q][j + qh] = dT'[q][j] (j < KH) ; dT[q][Lh + j' + qw] = dT'[q][KH + j'] : one lane per (q, slot), plain stores
@@ -214,15 +208,15 @@ __global__ __launch_bounds__(256, NSG == 1 ? 3 : (NSG == 2 ? 2 : 1)) void attn_b
     bf.w[0] = pack_bf16x2(d0.x, d0.y); bf.w[1] = pack_bf16x2(d0.z, d0.w);
     bf.w[2] = pack_bf16x2(d1.x, d1.y); bf.w[3] = pack_bf16x2(d1.z, d1.w);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UT; ++u) {
       const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(p.tblT + (int64_t)(16 * u + fr) * g.NT + 32 * s3 + 8 * fq);
       dq[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf.v, dq[u], 0, 0, 0);
     }
   }
   if (qp.valid) {
-    bf16_t* op = p.dqkv + (row_base + qp.tok) * ld + head * ATT_HD + 4 * fq;
+    bf16_t* op = p.dqkv + (row_base + qp.tok) * ld + head * HD + 4 * fq;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UT; ++u) {
       u32x2_t w;
       w.x = pack_bf16x2(dq[u][0], dq[u][1]);
       w.y = pack_bf16x2(dq[u][2], dq[u][3]);
@@ -236,8 +230,10 @@ __global__ __launch_bounds__(256, NSG == 1 ? 3 : (NSG == 2 ? 2 : 1)) void attn_b
 // of 64: dV^T += dO^T.P, dK^T += scale * Q^T.dS with the P / dS accumulator tiles reused as B operands. Q and
 // dO are staged row-major only; their transposes come from ds_read_b64_tr_b16. The rel-pos bias is the
 // product T'.G^T: T' (per query, hi + lo bf16 rows staged in LDS) times this lane's key indicator (registers).
-template <int NSG>
-__global__ __launch_bounds__(256, NSG == 4 ? 2 : 3) void attn_bwd_dkv_kernel(const AttnBwdParams p) {
+template <int NSG, int HD>
+__global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 4 ? 2 : 3)) void attn_bwd_dkv_kernel(const AttnBwdParams p) {
+  typedef AttHd<HD> H;
+  constexpr int KS = H::KS, UT = H::UT, ROWB = H::ROWB, CHS = H::CHS, CHV = H::CHV, RPI = H::RPI, NIT = ATT_QT / H::RPI;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const AttnGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -250,9 +246,9 @@ __global__ __launch_bounds__(256, NSG == 4 ? 2 : 3) void attn_bwd_dkv_kernel(con
   const int TLD = g.NT + 4;
   const int nsg = (g.KH + g.KW + 31) >> 5;
 
-  unsigned char* Q_lds = smem;                                   // [64][64] swizzled
-  unsigned char* dO_lds = smem + ATT_QT * ATT_HD * 2;
-  float* lse_lds = (float*)(smem + 2 * ATT_QT * ATT_HD * 2);     // [64] lse * log2(e); +huge for an absent query
+  unsigned char* Q_lds = smem;                                   // [64][hd] swizzled
+  unsigned char* dO_lds = smem + ATT_QT * ROWB;
+  float* lse_lds = (float*)(smem + 2 * ATT_QT * ROWB);           // [64] lse * log2(e); +huge for an absent query
   float* delta_lds = lse_lds + ATT_QT;                           // [64]
   unsigned char* TqH_lds = (unsigned char*)(delta_lds + ATT_QT); // [nsg][64][32 slots] bf16, hi part of T'/scale
   unsigned char* TqL_lds = TqH_lds + nsg * ATT_QT * ATT_GROW;    // lo part
@@ -264,14 +260,9 @@ __global__ __launch_bounds__(256, NSG == 4 ? 2 : 3) void attn_bwd_dkv_kernel(con
   // this lane's key (column of S / dP tiles) and its indicator slots
   const QueryPos kp = query_pos(g, wi, wj, k0 + wave * 16 + fr);
   const bool wave_active = k0 + wave * 16 < nq;
-  bf16x8_t kb[2], vb[2];
-  {
-    const bf16_t* kptr = p.qkv + (row_base + kp.tok) * ld + g.D + head * ATT_HD + 8 * fq;
-    kb[0] = *reinterpret_cast<const bf16x8_t*>(kptr);
-    kb[1] = *reinterpret_cast<const bf16x8_t*>(kptr + 32);
-    vb[0] = *reinterpret_cast<const bf16x8_t*>(kptr + g.D);
-    vb[1] = *reinterpret_cast<const bf16x8_t*>(kptr + g.D + 32);
-  }
+  bf16x8_t kb[KS], vb[KS];
+  att_load_row_frags<HD>(p.qkv + (row_base + kp.tok) * ld + g.D + head * HD, fq, true, kb);
+  att_load_row_frags<HD>(p.qkv + (row_base + kp.tok) * ld + 2 * g.D + head * HD, fq, true, vb);
   bf16x8_t gk[NSG];
   {
     const int jh = g.KH - 1 - kp.qh, jw = g.KH + g.KW - 1 - kp.qw;
@@ -288,46 +279,42 @@ __global__ __launch_bounds__(256, NSG == 4 ? 2 : 3) void attn_bwd_dkv_kernel(con
   }
   const float cs = g.scale * 1.4426950408889634f;
 
-  f32x4_t dk[4], dv[4];
+  f32x4_t dk[UT], dv[UT];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) { dk[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[u] = dk[u]; }
+  for (int u = 0; u < UT; ++u) { dk[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[u] = dk[u]; }
 
   for (int qc = 0; qc < nq; qc += ATT_QT) {
     // ---- stage Q / dO (row-major), lse, delta and the T' rows of the chunk's queries. All global loads first
     // and unconditional (an absent query reads the window's first token and is zeroed): one round trip.
-    const int ch = tid & 7;
-    u32x4_t qv[2], dv_[2], ov[2];
-    float lsev[2];
-    bool qok[2];
+    const int ch = tid % CHS, chl = ch < CHV ? ch : CHV - 1;       // slots >= CHV hold zeros
+    u32x4_t qv[NIT], dv_[NIT], ov[NIT];
+    float lsev[NIT];
+    bool qok[NIT];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const QueryPos qq = query_pos(g, wi, wj, qc + it * 32 + (tid >> 3));
-      qv[it] = *reinterpret_cast<const u32x4_t*>(p.qkv + (row_base + qq.tok) * ld + head * ATT_HD + ch * 8);
-      dv_[it] = *reinterpret_cast<const u32x4_t*>(p.dout + (row_base + qq.tok) * g.D + head * ATT_HD + ch * 8);
-      ov[it] = *reinterpret_cast<const u32x4_t*>(p.out + (row_base + qq.tok) * g.D + head * ATT_HD + ch * 8);
+    for (int it = 0; it < NIT; ++it) {
+      const QueryPos qq = query_pos(g, wi, wj, qc + it * RPI + tid / CHS);
+      qv[it] = *reinterpret_cast<const u32x4_t*>(p.qkv + (row_base + qq.tok) * ld + head * HD + chl * 8);
+      dv_[it] = *reinterpret_cast<const u32x4_t*>(p.dout + (row_base + qq.tok) * g.D + head * HD + chl * 8);
+      ov[it] = *reinterpret_cast<const u32x4_t*>(p.out + (row_base + qq.tok) * g.D + head * HD + chl * 8);
       lsev[it] = p.lse[((int64_t)gi * g.heads + head) * T + qq.tok];
       qok[it] = qq.valid;
     }
     const QueryPos qw_ = query_pos(g, wi, wj, qc + wave * 16 + fr);      // this wave's 16 queries: table product
-    bf16x8_t qfx[2];
-    {
-      const bf16_t* qptr = p.qkv + (row_base + qw_.tok) * ld + head * ATT_HD + 8 * fq;
-      qfx[0] = *reinterpret_cast<const bf16x8_t*>(qptr);
-      qfx[1] = *reinterpret_cast<const bf16x8_t*>(qptr + 32);
-      if (!qw_.valid) { qfx[0] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}; qfx[1] = qfx[0]; }
-    }
+    bf16x8_t qfx[KS];
+    att_load_row_frags<HD>(p.qkv + (row_base + qw_.tok) * ld + head * HD, fq, qw_.valid, qfx);
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int ql = it * 32 + (tid >> 3);
-      if (!qok[it]) { qv[it] = (u32x4_t){0u, 0u, 0u, 0u}; dv_[it] = qv[it]; ov[it] = qv[it]; }
-      *reinterpret_cast<u32x4_t*>(Q_lds + ql * 128 + ((ch ^ kswz(ql)) << 4)) = qv[it];
-      *reinterpret_cast<u32x4_t*>(dO_lds + ql * 128 + ((ch ^ kswz(ql)) << 4)) = dv_[it];
+    for (int it = 0; it < NIT; ++it) {
+      const int ql = it * RPI + tid / CHS;
+      if (!qok[it] || ch >= CHV) { qv[it] = (u32x4_t){0u, 0u, 0u, 0u}; dv_[it] = qv[it]; ov[it] = qv[it]; }
+      *reinterpret_cast<u32x4_t*>(Q_lds + ql * ROWB + ((ch ^ kswz(ql)) << 4)) = qv[it];
+      *reinterpret_cast<u32x4_t*>(dO_lds + ql * ROWB + ((ch ^ kswz(ql)) << 4)) = dv_[it];
       const unsigned int dw_[4] = {dv_[it].x, dv_[it].y, dv_[it].z, dv_[it].w}, ow_[4] = {ov[it].x, ov[it].y, ov[it].z, ov[it].w};
       float dl = 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) dl += bf16_lo(dw_[e]) * bf16_lo(ow_[e]) + bf16_hi(dw_[e]) * bf16_hi(ow_[e]);
       dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64); dl += __shfl_xor(dl, 4, 64);
+      if (CHS > 8) dl += __shfl_xor(dl, 8, 64);
       if (ch == 0) {
         delta_lds[ql] = dl;
         lse_lds[ql] = qok[it] ? lsev[it] * 1.4426950408889634f : 1e30f;     // absent query: P = exp2(-huge) = 0
@@ -335,7 +322,7 @@ __global__ __launch_bounds__(256, NSG == 4 ? 2 : 3) void attn_bwd_dkv_kernel(con
     }
     {
       float* Trow = T_lds + (wave * 16 + fr) * TLD;
-      att_table_product(p.tbl, g.NT, qfx, Trow, fr, fq);
+      att_table_product<HD>(p.tbl, g.NT, qfx, Trow, fr, fq);
       bf16x8_t th[NSG], tl[NSG];
       att_slot_fragments<NSG>(g, Trow, qw_.qh, qw_.qw, fq, nsg, th, tl);
       const int ql = wave * 16 + fr;
@@ -359,8 +346,8 @@ __global__ __launch_bounds__(256, NSG == 4 ? 2 : 3) void attn_bwd_dkv_kernel(con
           f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = s;
           const int qr = q32 * 32 + 16 * sub + fr;
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            const int off = qr * 128 + (((fq + 4 * ks) ^ kswz(qr)) << 4);
+          for (int ks = 0; ks < KS; ++ks) {
+            const int off = qr * ROWB + (((fq + 4 * ks) ^ kswz(qr)) << 4);
             s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(Q_lds + off), kb[ks], s, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(dO_lds + off), vb[ks], dp, 0, 0, 0);
           }
@@ -387,11 +374,11 @@ __global__ __launch_bounds__(256, NSG == 4 ? 2 : 3) void attn_bwd_dkv_kernel(con
         // dV^T += dO^T . P ; dK^T += Q^T . dS   (query slot j <-> query 16*(j>>2) + 4*fq + (j&3))
         const int qrow = q32 * 32 + 4 * fq + (fr >> 2);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int off = qrow * 128 + (((2 * u + ((fr >> 1) & 1)) ^ kswz(qrow)) << 4) + ((fr & 1) << 3);
+        for (int u = 0; u < UT; ++u) {
+          const int off = qrow * ROWB + (((2 * u + ((fr >> 1) & 1)) ^ kswz(qrow)) << 4) + ((fr & 1) << 3);
           union { bf16x8_t v; s16x4_t h[2]; } af, bf;
-          af.h[0] = att_tr_read(dO_lds + off); af.h[1] = att_tr_read(dO_lds + off + 16 * 128);
-          bf.h[0] = att_tr_read(Q_lds + off); bf.h[1] = att_tr_read(Q_lds + off + 16 * 128);
+          af.h[0] = att_tr_read(dO_lds + off); af.h[1] = att_tr_read(dO_lds + off + 16 * ROWB);
+          bf.h[0] = att_tr_read(Q_lds + off); bf.h[1] = att_tr_read(Q_lds + off + 16 * ROWB);
           dv[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, pf.v, dv[u], 0, 0, 0);
           dk[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf.v, dsf.v, dk[u], 0, 0, 0);
         }
@@ -399,9 +386,9 @@ __global__ __launch_bounds__(256, NSG == 4 ? 2 : 3) void attn_bwd_dkv_kernel(con
     }
   }
   if (kp.valid) {
-    bf16_t* op = p.dqkv + (row_base + kp.tok) * ld + g.D + head * ATT_HD + 4 * fq;
+    bf16_t* op = p.dqkv + (row_base + kp.tok) * ld + g.D + head * HD + 4 * fq;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UT; ++u) {
       u32x2_t w;
       w.x = pack_bf16x2(dk[u][0], dk[u][1]); w.y = pack_bf16x2(dk[u][2], dk[u][3]);
       *reinterpret_cast<u32x2_t*>(op + 16 * u) = w;
@@ -428,30 +415,35 @@ extern "C" int mfnet_attn_bwd(const void* qkv, const float* qkv_bias, const void
   p.out = (const bf16_t*)out; p.dout = (const bf16_t*)dout; p.lse = lse; p.dqkv = (bf16_t*)dqkv;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) { mfnet_set_error("attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MFNET_ERR_HIP; }
+    const void* fns[12] = {(const void*)attn_bwd_dq_kernel<1, 64>, (const void*)attn_bwd_dq_kernel<2, 64>, (const void*)attn_bwd_dq_kernel<4, 64>,
+                           (const void*)attn_bwd_dkv_kernel<1, 64>, (const void*)attn_bwd_dkv_kernel<2, 64>, (const void*)attn_bwd_dkv_kernel<4, 64>,
+                           (const void*)attn_bwd_dq_kernel<1, 80>, (const void*)attn_bwd_dq_kernel<2, 80>, (const void*)attn_bwd_dq_kernel<4, 80>,
+                           (const void*)attn_bwd_dkv_kernel<1, 80>, (const void*)attn_bwd_dkv_kernel<2, 80>, (const void*)attn_bwd_dkv_kernel<4, 80>};
+    for (int i = 0; i < 12; ++i) {
+      hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) { mfnet_set_error("attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MFNET_ERR_HIP; }
+    }
     attr_set = true;
   }
   const int nsg = (p.g.KH + p.g.KW + 31) / 32;
+  const int rowb = hd <= 64 ? AttHd<64>::ROWB : AttHd<80>::ROWB;
   const size_t TL = (size_t)ATT_QT * (p.g.NT + 4) * 4;
-  const size_t lds_dq = (size_t)att_region_a(p.g.NT) + (size_t)nsg * ATT_KC * ATT_GROW;
-  const size_t lds_dkv = 2 * (size_t)ATT_QT * ATT_HD * 2 + 2 * ATT_QT * 4 + 2 * (size_t)nsg * ATT_QT * ATT_GROW + TL;
+  const size_t lds_dq = (size_t)att_region_a(p.g.NT, rowb) + (size_t)nsg * ATT_KC * ATT_GROW;
+  const size_t lds_dkv = 2 * (size_t)ATT_QT * rowb + 2 * ATT_QT * 4 + 2 * (size_t)nsg * ATT_QT * ATT_GROW + TL;
   MF_CHECK_ARG(lds_dq <= 160 * 1024 && lds_dkv <= 160 * 1024, "attn_bwd: LDS demand too large");
   // the two kernels write disjoint column ranges of dqkv (q | k,v); window mode leaves nothing unwritten
   dim3 grid_q((unsigned)attn_query_tiles(p.g), (unsigned)heads, (unsigned)G);
   MF_CHECK_ARG(grid_q.z <= 65535 && grid_q.y <= 65535, "attn_bwd: grid too large");
-  if (nsg <= 1) hipLaunchKernelGGL(attn_bwd_dq_kernel<1>, grid_q, dim3(256), lds_dq, stream, p);
-  else if (nsg == 2) hipLaunchKernelGGL(attn_bwd_dq_kernel<2>, grid_q, dim3(256), lds_dq, stream, p);
-  else hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, grid_q, dim3(256), lds_dq, stream, p);
+#define ATT_BWD(KERNEL, LDS, HDV)                                                                          \
+  do {                                                                                                     \
+    if (nsg <= 1) hipLaunchKernelGGL((KERNEL<1, HDV>), grid_q, dim3(256), LDS, stream, p);                 \
+    else if (nsg == 2) hipLaunchKernelGGL((KERNEL<2, HDV>), grid_q, dim3(256), LDS, stream, p);            \
+    else hipLaunchKernelGGL((KERNEL<4, HDV>), grid_q, dim3(256), LDS, stream, p);                          \
+  } while (0)
+  if (hd == 64) ATT_BWD(attn_bwd_dq_kernel, lds_dq, 64); else ATT_BWD(attn_bwd_dq_kernel, lds_dq, 80);
   MF_LAUNCH_CHECK("attn_bwd_dq");
-  if (nsg <= 1) hipLaunchKernelGGL(attn_bwd_dkv_kernel<1>, grid_q, dim3(256), lds_dkv, stream, p);
-  else if (nsg == 2) hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, grid_q, dim3(256), lds_dkv, stream, p);
-  else hipLaunchKernelGGL(attn_bwd_dkv_kernel<4>, grid_q, dim3(256), lds_dkv, stream, p);
+  if (hd == 64) ATT_BWD(attn_bwd_dkv_kernel, lds_dkv, 64); else ATT_BWD(attn_bwd_dkv_kernel, lds_dkv, 80);
   MF_LAUNCH_CHECK("attn_bwd_dkv");
+#undef ATT_BWD
   return MFNET_OK;
 }

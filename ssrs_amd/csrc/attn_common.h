@@ -13,7 +13,20 @@
 #pragma once
 #include "common.h"
 
-#define ATT_HD 64          // head dim (ViT-B / ViT-L)
+// Head dim: 64 (ViT-B / ViT-L) or 80 (ViT-H: 1280 / 16). The kernels are templated on it through AttHd: 80 runs
+// three 32-wide MFMA k-steps over a zero-padded 96 and five 16-wide output tiles; LDS rows become 256 B (16 chunk
+// slots, 10 with data, 2 zero, 4 unused) so that the XOR swizzle - which only touches the low three chunk bits - still
+// stays inside the row.
+template <int HD> struct AttHd {
+  static_assert(HD % 16 == 0 && HD >= 32 && HD <= 128, "head dim must be a multiple of 16 in [32, 128]");
+  static constexpr int KS = (HD + 31) / 32;          // MFMA k-steps over the head dim
+  static constexpr int UT = HD / 16;                 // 16-wide head-dim tiles of O / dQ / dK / dV
+  static constexpr int ROWB = HD <= 64 ? 128 : 256;  // bytes per LDS row of a [row][hd] bf16 image
+  static constexpr int CHS = ROWB / 16;              // 16-B chunk slots per row
+  static constexpr int CHV = HD / 8;                 // chunks that hold data; slots CHV .. 4*KS-1 are zero
+  static constexpr int RPI = 256 / CHS;              // rows one staging pass of the 256 threads covers
+  static constexpr int HDP = 32 * KS;                // row length of the (zero padded) rel-pos table
+};
 #define ATT_KC 128         // keys resident in LDS per chunk (small enough for 2-3 workgroups per CU)
 #define ATT_QT 64          // queries per workgroup (4 waves x 16)
 #define ATT_VT_LD (ATT_KC + 8)   // bf16 elements per row of the transposed [hd][key] images
@@ -61,8 +74,8 @@ __device__ __forceinline__ int gswz(int row) { return (row >> 2) & 3; }   // sam
 #define ATT_GROW 64        // bytes per key row of one 32-slot indicator image
 
 // LDS bytes shared by the K / V images (key loop) and the T table (before it)
-__host__ __device__ inline int att_region_a(int NT) {
-  const int kv = 2 * ATT_KC * ATT_HD * 2, t = ATT_QT * (NT + 4) * 4;
+__host__ __device__ inline int att_region_a(int NT, int rowb) {
+  const int kv = 2 * ATT_KC * rowb, t = ATT_QT * (NT + 4) * 4;
   return kv > t ? kv : t;
 }
 
@@ -89,33 +102,47 @@ __device__ __forceinline__ void att_locate_tile(const AttnGeom& g, int t, int* w
 // issued before the first MFMA (rows beyond NT re-read the last tile), so the product costs one memory
 // round trip instead of NT/16.
 #define ATT_MAX_NT16 16
-__device__ __forceinline__ void att_table_product(const bf16_t* tbl, int NT, const bf16x8_t (&qf)[2], float* Trow, int fr, int fq) {
+template <int HD>
+__device__ __forceinline__ void att_table_product(const bf16_t* tbl, int NT, const bf16x8_t (&qf)[AttHd<HD>::KS], float* Trow, int fr, int fq) {
+  constexpr int KS = AttHd<HD>::KS, HDP = AttHd<HD>::HDP;
   const int nt16 = NT >> 4;
   for (int t0 = 0; t0 < nt16; t0 += 4) {
-    bf16x8_t a0[4], a1[4];
+    bf16x8_t a[4][KS];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int t = min(t0 + i, nt16 - 1);
-      const bf16_t* tp = tbl + (int64_t)(16 * t + fr) * ATT_HD + 8 * fq;
-      a0[i] = *reinterpret_cast<const bf16x8_t*>(tp);
-      a1[i] = *reinterpret_cast<const bf16x8_t*>(tp + 32);
+      const bf16_t* tp = tbl + (int64_t)(16 * t + fr) * HDP + 8 * fq;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) a[i][ks] = *reinterpret_cast<const bf16x8_t*>(tp + 32 * ks);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (t0 + i < nt16) {
         f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], qf[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], qf[1], acc, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], qf[ks], acc, 0, 0, 0);
         *reinterpret_cast<float4*>(Trow + 16 * (t0 + i) + 4 * fq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
       }
     }
   }
 }
 
+// This lane's k-step fragments of one [., hd] bf16 row (q, k, v, dO, O): k-step ks covers head dims 32 ks + 8 fq ..+7;
+// fragments past the head dim (hd = 80: the upper half of the third k-step) are zero and are never loaded.
+template <int HD>
+__device__ __forceinline__ void att_load_row_frags(const bf16_t* row, int fq, bool valid, bf16x8_t (&f)[AttHd<HD>::KS]) {
+#pragma unroll
+  for (int ks = 0; ks < AttHd<HD>::KS; ++ks) {
+    const bool in = 32 * ks + 8 * fq < HD;
+    f[ks] = *reinterpret_cast<const bf16x8_t*>(row + (in ? 32 * ks + 8 * fq : 8 * fq));
+    if (!in || !valid) f[ks] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+  }
+}
+
 // 16-B chunk `ch` of a padded key's K and V rows: the qkv bias (fp32) rounded to bf16
 struct PaddedKV { u32x4_t k, v; };
-__device__ __forceinline__ PaddedKV att_padded_kv(const float* qkv_bias, int D, int head, int ch) {
-  const float* bk = qkv_bias + D + head * ATT_HD + ch * 8;
+__device__ __forceinline__ PaddedKV att_padded_kv(const float* qkv_bias, int D, int head, int hd, int ch) {
+  const float* bk = qkv_bias + D + head * hd + ch * 8;
   const float4 a = *reinterpret_cast<const float4*>(bk), b = *reinterpret_cast<const float4*>(bk + 4);
   const float4 c = *reinterpret_cast<const float4*>(bk + D), d = *reinterpret_cast<const float4*>(bk + D + 4);
   PaddedKV r;

@@ -66,14 +66,16 @@ def _resize_rel(rel: torch.Tensor, need: int) -> torch.Tensor:
 
 
 def build_rel_table(rel_h: torch.Tensor, rel_w: torch.Tensor, kh: int, kw: int):
-    """-> (tbl [NT,hd] bf16, tblT [hd,NT] bf16, Lh, Lw): rows [0,Lh) the h table, [Lh,Lh+Lw) the w
+    """-> (tbl [NT, hd rounded up to 32] bf16, tblT [hd,NT] bf16, Lh, Lw): rows [0,Lh) the h table, [Lh,Lh+Lw) the w
     table (both resized to 2k-1 rows), zero rows up to a multiple of 32."""
     Lh, Lw = 2 * kh - 1, 2 * kw - 1
     t = torch.cat([_resize_rel(rel_h.detach().float(), Lh), _resize_rel(rel_w.detach().float(), Lw)], 0)
     NT = ((Lh + Lw + 31) // 32) * 32
-    full = torch.zeros(NT, t.shape[1], dtype=torch.float32, device=t.device)
-    full[:Lh + Lw] = t
-    return full.to(BF).contiguous(), full.t().contiguous().to(BF).contiguous(), Lh, Lw
+    hd = t.shape[1]
+    hdp = (hd + 31) // 32 * 32                      # the kernels run 32-wide k-steps over the head dim (80 -> 96, zeros)
+    full = torch.zeros(NT, hdp, dtype=torch.float32, device=t.device)
+    full[:Lh + Lw, :hd] = t
+    return full.to(BF).contiguous(), full[:, :hd].t().contiguous().to(BF).contiguous(), Lh, Lw
 
 
 def _rel_tables(attn: nn.Module, kh: int, kw: int):

@@ -220,27 +220,30 @@ def _rel_tables(rel_h, rel_w, k):
     return build_rel_table(rel_h, rel_w, k, k)
 
 
-@pytest.mark.parametrize("S,ws,heads,G", [(16, 14, 2, 2), (16, 0, 2, 2), (20, 14, 3, 1), (20, 0, 1, 2), (16, 14, 12, 4),
-                                          (32, 0, 1, 1), (64, 14, 1, 1), (64, 0, 1, 1)])   # 2 and 4 slot groups; 1024-px grid
-def test_attention_fwd_bwd(ops, S, ws, heads, G):
-    D = heads * 64
+@pytest.mark.parametrize("S,ws,heads,G,hd", [(16, 14, 2, 2, 64), (16, 0, 2, 2, 64), (20, 14, 3, 1, 64), (20, 0, 1, 2, 64), (16, 14, 12, 4, 64),
+                                             (32, 0, 1, 1, 64), (64, 14, 1, 1, 64), (64, 0, 1, 1, 64),   # 2 and 4 slot groups; 1024-px grid
+                                             (16, 14, 3, 2, 80), (16, 0, 2, 2, 80), (20, 14, 1, 1, 80), (32, 0, 1, 1, 80), (64, 14, 1, 1, 80),
+                                             (64, 0, 1, 1, 80)])                                         # ViT-H head dim
+def test_attention_fwd_bwd(ops, S, ws, heads, G, hd):
+    D = heads * hd
     qkv = rnd(G * S * S, 3 * D, seed=1, scale=1.5).to(torch.bfloat16)
     bias = rnd(3 * D, seed=2)
     L = 27 if ws > 0 else 127
-    rel_h = rnd(L, 64, seed=3, scale=0.2)
-    rel_w = rnd(L, 64, seed=4, scale=0.2)
+    rel_h = rnd(L, hd, seed=3, scale=0.2)
+    rel_w = rnd(L, hd, seed=4, scale=0.2)
     k = ws if ws > 0 else S
     tbl, tblT, Lh, Lw = _rel_tables(rel_h, rel_w, k)
-    out, lse = ops.attn_fwd(qkv, bias, tbl, G, S, S, heads, ws, Lh, Lw, 64 ** -0.5)
+    assert tbl.shape[1] % 32 == 0 and tblT.shape[0] == hd
+    out, lse = ops.attn_fwd(qkv, bias, tbl, G, S, S, heads, ws, Lh, Lw, hd ** -0.5)
     # reference on the same rounded operands (bf16 tables, bf16 padded-key bias), fp64
-    rh = tbl[:Lh].double().cpu()
-    rw = tbl[Lh:Lh + Lw].double().cpu()
+    rh = tbl[:Lh, :hd].double().cpu()
+    rw = tbl[Lh:Lh + Lw, :hd].double().cpu()
     qd = qkv.double().cpu().requires_grad_()
     ref = _attn_reference(qd, bf16r(bias).double().cpu(), rh, rw, G, S, heads, ws)
     assert rel_err(out.float(), ref.detach()) < 1e-2
     dout = rnd(G * S * S, D, seed=5).to(torch.bfloat16)
     ref.backward(dout.double().cpu())
-    dqkv = ops.attn_bwd(qkv, bias, tbl, tblT, out, dout, lse, G, S, S, heads, ws, Lh, Lw, 64 ** -0.5)
+    dqkv = ops.attn_bwd(qkv, bias, tbl, tblT, out, dout, lse, G, S, S, heads, ws, Lh, Lw, hd ** -0.5)
     for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
         e = rel_err(dqkv[:, sl].float(), qd.grad[:, sl])
         assert e < 2e-2, (name, e)

@@ -31,11 +31,11 @@ def _u(key, shape):
     return torch.from_numpy(detfill.uniform(key, shape)).float()
 
 
-def _block(kind, ws):
+def _block(kind, ws, dim=128, heads=2):
     from ssrs_amd.vit import LoraBlock
     from ssrs_amd.vit_adapter import AdapterFusionBlock
     cls = LoraBlock if kind == "lora" else AdapterFusionBlock
-    return cls(args=_args("sam_lora" if kind == "lora" else "sam_adpt"), dim=128, num_heads=2, mlp_ratio=4.0,
+    return cls(args=_args("sam_lora" if kind == "lora" else "sam_adpt"), dim=dim, num_heads=heads, mlp_ratio=4.0,
                qkv_bias=True, norm_layer=functools.partial(nn.LayerNorm, eps=1e-6), act_layer=nn.GELU,
                use_rel_pos=True, rel_pos_zero_init=True, window_size=ws, input_size=(64, 64))
 
@@ -69,6 +69,41 @@ def test_block_fwd_bwd_vs_reference(kind, ws, S):
             worst[n] = rel_err(p.grad, g["g/" + n])
     # scalar mixing weights are one cancellation-heavy full reduction over bf16-rounded products
     bad = {k: v for k, v in worst.items() if v > (1e-1 if g["g/" + k].size == 1 else 3e-2)}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("kind", ["lora", "adpt"])
+@pytest.mark.parametrize("ws", [14, 0])
+def test_block_head_dim_80_vs_oracle(kind, ws):
+    """ViT-H's head dim (1280 / 16 = 80; here dim 640, 8 heads): block forward, input gradients and PEFT gradients against
+    the float64 oracle restatement of the block (which the dim-128 block goldens of the reference pin)."""
+    from oracle import mfnet_ref as R
+    tag, S, dim = f"block80_{kind}_w{ws}", 16, 640
+    blk = _block(kind, ws, dim, 8)
+    blk.load_state_dict(detfill.fill_state_dict(blk.state_dict(), tag + "/"))
+    token = "lora_" if kind == "lora" else "Adapter"
+    trainable = [n for n, _ in blk.named_parameters() if token in n]
+    for n, p in blk.named_parameters():
+        p.requires_grad = n in trainable
+    sd = {k: v.detach().double().clone().requires_grad_(k in trainable) for k, v in blk.state_dict().items() if v.dtype.is_floating_point}
+    blk = blk.cuda()
+    x0, y0 = _u(tag + "/x", (1, S, S, dim)), _u(tag + "/y", (1, S, S, dim))
+    gx, gy = _u(tag + "/gx", (1, S, S, dim)), _u(tag + "/gy", (1, S, S, dim))
+    xr, yr = x0.double().requires_grad_(), y0.double().requires_grad_()
+    fn = R.lora_block if kind == "lora" else R.adapter_fusion_block
+    rx, ry = fn(sd, "", xr, yr, 8, ws)
+    ((rx * gx.double()).sum() + (ry * gy.double()).sum()).backward()
+    x, y = x0.cuda().requires_grad_(), y0.cuda().requires_grad_()
+    ox, oy = blk(x, y)
+    assert rel_err(ox, rx.detach()) < BF16_TOL and rel_err(oy, ry.detach()) < BF16_TOL
+    ((ox * gx.cuda()).sum() + (oy * gy.cuda()).sum()).backward()
+    assert rel_err(x.grad, xr.grad) < BF16_TOL and rel_err(y.grad, yr.grad) < BF16_TOL
+    bad = {}
+    for n, p in blk.named_parameters():
+        if n in trainable:
+            e = rel_err(p.grad, sd[n].grad)
+            if e > (1e-1 if p.numel() == 1 else 3e-2):
+                bad[n] = e
     assert not bad, bad
 
 
@@ -206,10 +241,11 @@ def test_vitb_eval_logits_vs_reference():
     _check_masks(out, g, tgt)
 
 
-@pytest.mark.parametrize("mod,encoder,tile,batch", [("sam_adpt", "vit_b", 256, 2), ("sam_lora", "vit_b", 256, 2), ("sam_lora", "vit_l", 512, 1)])
+@pytest.mark.parametrize("mod,encoder,tile,batch", [("sam_adpt", "vit_b", 256, 2), ("sam_lora", "vit_b", 256, 2), ("sam_lora", "vit_l", 512, 1),
+                                                    ("sam_lora", "vit_h", 256, 1), ("sam_adpt", "vit_h", 256, 1)])
 def test_full_size_train_steps_run_and_learn(mod, encoder, tile, batch):
-    """SURVEY 8(d) configurations at their real widths (768 / 1024 channels, 192-wide adapters, a 32x32 token grid with
-    9 windows for ViT-L at 512 px) through the graph-captured engine: every kernel accepts its shapes, the loss is finite
+    """SURVEY 8(d) configurations at their real widths (768 / 1024 / 1280 channels, head dim 80 for ViT-H, adapters, a
+    32x32 token grid with 9 windows for ViT-L at 512 px) through the graph-captured engine: every kernel accepts its shapes, the loss is finite
     and falls when the same batch is stepped on repeatedly."""
     from ssrs_amd.trainer import TrainEngine
     from ssrs_amd.unetformer_mmsam import UNetFormer
