@@ -17,6 +17,7 @@
 // indicator image staged beside K. T' is split hi + lo in bf16 (two k-steps), so the bias keeps fp32-level
 // accuracy, and it is pre-divided by `scale` so one multiply serves the whole logit.
 #include "attn_common.h"
+#include <stdlib.h>
 
 struct AttnFwdParams {
   AttnGeom g;
@@ -27,7 +28,11 @@ struct AttnFwdParams {
   float* lse;             // [G, heads, T]
 };
 
-template <int NSG, int HD>      // NSG: 32-slot groups of the indicator product, ceil((KH + KW) / 32) rounded up to 1, 2 or 4
+// ROWT ("row tiles"): global attention over a grid whose rows are 64 keys wide (1024-px inputs): every 64-key tile is one
+// key row, so the bias of a tile is separable in registers - a per-query scalar (the h term of that row) plus a per-lane
+// 4 x 4 patch of the w term that is the same for every tile - and the indicator product (8 of the 12 MFMA k-steps per
+// tile at KH + KW = 128) disappears.
+template <int NSG, int HD, bool ROWT>      // NSG: 32-slot groups of the indicator product, ceil((KH + KW) / 32) rounded up to 1, 2 or 4
 __global__ __launch_bounds__(256, (NSG == 1 && HD <= 64) ? 4 : 2) void attn_fwd_kernel(const AttnFwdParams p) {
   typedef AttHd<HD> H;
   constexpr int KS = H::KS, UT = H::UT, ROWB = H::ROWB, CHS = H::CHS, CHV = H::CHV, RPI = H::RPI, NIT = ATT_KC / H::RPI;
@@ -84,7 +89,18 @@ __global__ __launch_bounds__(256, (NSG == 1 && HD <= 64) ? 4 : 2) void attn_fwd_
   float* Trow = T_lds + (wave * 16 + fr) * TLD;
   att_table_product<HD>(p.tbl, g.NT, qf, Trow, fr, fq);
   bf16x8_t tqh[NSG], tql[NSG];
-  att_slot_fragments<NSG>(g, Trow, qp.qh, qp.qw, fq, nsg, tqh, tql);
+  float wb[4][4];                                                  // ROWT: bias / scale of this lane's keys 16 t + 4 fq + r (w term)
+  float* Thq = (float*)G_lds;                                      // ROWT: [64 queries][KH] h term / scale
+  if (ROWT) {
+    const float inv = 1.0f / g.scale;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wb[t][r] = Trow[g.Lh + (g.KW - 1 - (16 * t + 4 * fq + r)) + qp.qw] * inv;
+    for (int j = fq; j < g.KH; j += 4) Thq[(wave * 16 + fr) * g.KH + j] = Trow[(g.KH - 1 - j) + qp.qh] * inv;
+  } else {
+    att_slot_fragments<NSG>(g, Trow, qp.qh, qp.qw, fq, nsg, tqh, tql);
+  }
 
   float m_run = -INFINITY, l_run = 0.f;
   const float cs = g.scale * 1.4426950408889634f;                  // logits are scale * acc; exp via exp2
@@ -103,16 +119,17 @@ __global__ __launch_bounds__(256, (NSG == 1 && HD <= 64) ? 4 : 2) void attn_fwd_
       *reinterpret_cast<u32x4_t*>(K_lds + kl * ROWB + ((ch ^ kswz(kl)) << 4)) = k4;
       *reinterpret_cast<u32x4_t*>(V_lds + kl * ROWB + ((ch ^ kswz(kl)) << 4)) = v4;
     }
-    att_stage_indicator(g, G_lds, kc, Nk, nsg, tid);
+    if (!ROWT) att_stage_indicator(g, G_lds, kc, Nk, nsg, tid);
     __syncthreads();
     const int kvalid = min(ATT_KC, Nk - kc);
     if (wave_active) {
       for (int kt = 0; kt * 64 < kvalid; ++kt) {
-        // ---- S^T tiles (16 keys x 16 queries each): K.Q^T + G.T'^T
+        // ---- S^T tiles (16 keys x 16 queries each): K.Q^T + G.T'^T (ROWT: the bias is the accumulator's initial value)
         f32x4_t s[4];
+        const float hb = ROWT ? Thq[(wave * 16 + fr) * g.KH + ((kc + kt * 64) >> 6)] : 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          s[t] = ROWT ? (f32x4_t){wb[t][0] + hb, wb[t][1] + hb, wb[t][2] + hb, wb[t][3] + hb} : (f32x4_t){0.f, 0.f, 0.f, 0.f};
           const int kr = kt * 64 + 16 * t + fr;
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
@@ -121,7 +138,7 @@ __global__ __launch_bounds__(256, (NSG == 1 && HD <= 64) ? 4 : 2) void attn_fwd_
           }
 #pragma unroll
           for (int c = 0; c < NSG; ++c) {
-            if (c < nsg) {
+            if (!ROWT && c < nsg) {
               const bf16x8_t gf = *reinterpret_cast<const bf16x8_t*>(G_lds + c * (ATT_KC * ATT_GROW) + kr * ATT_GROW + ((fq ^ gswz(kr)) << 4));
               s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, tqh[c], s[t], 0, 0, 0);
               s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, tql[c], s[t], 0, 0, 0);
@@ -217,6 +234,9 @@ static size_t attn_fwd_lds(const AttnGeom& g, int rowb) {
   return (size_t)att_region_a(g.NT, rowb) + (size_t)((g.KH + g.KW + 31) / 32) * ATT_KC * ATT_GROW;
 }
 
+// global attention whose key rows are exactly one 64-key tile wide: the separable-bias (ROWT) kernels apply
+bool attn_row_tiles(const AttnGeom& g) { return g.ws == 0 && g.KW == 64 && g.KH <= 64 && getenv("MFNET_ATTN_NO_ROWT") == nullptr; }
+
 // number of (window, 64-query tile) pairs of one image = grid.x of the query-tiled kernels
 int attn_query_tiles(const AttnGeom& g) {
   int n = 0;
@@ -241,9 +261,10 @@ extern "C" int mfnet_attn_fwd(const void* qkv, const float* qkv_bias, const void
   const size_t lds = attn_fwd_lds(p.g, rowb);
   static bool attr_set = false;
   if (!attr_set) {
-    const void* fns[6] = {(const void*)attn_fwd_kernel<1, 64>, (const void*)attn_fwd_kernel<2, 64>, (const void*)attn_fwd_kernel<4, 64>,
-                          (const void*)attn_fwd_kernel<1, 80>, (const void*)attn_fwd_kernel<2, 80>, (const void*)attn_fwd_kernel<4, 80>};
-    for (int i = 0; i < 6; ++i) {
+    const void* fns[8] = {(const void*)attn_fwd_kernel<1, 64, false>, (const void*)attn_fwd_kernel<2, 64, false>, (const void*)attn_fwd_kernel<4, 64, false>,
+                          (const void*)attn_fwd_kernel<1, 80, false>, (const void*)attn_fwd_kernel<2, 80, false>, (const void*)attn_fwd_kernel<4, 80, false>,
+                          (const void*)attn_fwd_kernel<4, 64, true>, (const void*)attn_fwd_kernel<4, 80, true>};
+    for (int i = 0; i < 8; ++i) {
       hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) { mfnet_set_error("attn_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MFNET_ERR_HIP; }
     }
@@ -256,9 +277,10 @@ extern "C" int mfnet_attn_fwd(const void* qkv, const float* qkv_bias, const void
   const int nsg = (p.g.KH + p.g.KW + 31) / 32;
 #define ATT_FWD(HDV)                                                                                   \
   do {                                                                                                 \
-    if (nsg <= 1) hipLaunchKernelGGL((attn_fwd_kernel<1, HDV>), grid, dim3(256), lds, stream, p);      \
-    else if (nsg == 2) hipLaunchKernelGGL((attn_fwd_kernel<2, HDV>), grid, dim3(256), lds, stream, p); \
-    else hipLaunchKernelGGL((attn_fwd_kernel<4, HDV>), grid, dim3(256), lds, stream, p);               \
+    if (attn_row_tiles(p.g)) hipLaunchKernelGGL((attn_fwd_kernel<4, HDV, true>), grid, dim3(256), lds, stream, p);   \
+    else if (nsg <= 1) hipLaunchKernelGGL((attn_fwd_kernel<1, HDV, false>), grid, dim3(256), lds, stream, p);        \
+    else if (nsg == 2) hipLaunchKernelGGL((attn_fwd_kernel<2, HDV, false>), grid, dim3(256), lds, stream, p);        \
+    else hipLaunchKernelGGL((attn_fwd_kernel<4, HDV, false>), grid, dim3(256), lds, stream, p);                      \
   } while (0)
   if (hd == 64) ATT_FWD(64); else ATT_FWD(80);
 #undef ATT_FWD

@@ -31,8 +31,10 @@ struct AttnBwdParams {
 // Same structure as attn_fwd_kernel (attn.hip): compact (window, tile) grid, K / V row-major in LDS, rel-pos
 // bias as the indicator product G.T'^T. The two transposed operands of this kernel, K^T (dQ^T += K^T.dS^T) and
 // G^T (dT'^T += G^T.dS^T), are read from the SAME row-major images with ds_read_b64_tr_b16.
-template <int NSG, int HD>
-__global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : (NSG == 2 ? 2 : 1))) void attn_bwd_dq_kernel(const AttnBwdParams p) {
+// ROWT (see attn_fwd_kernel): the bias enters as the initial accumulator; its gradient needs no indicator product either -
+// the w part is the lane's own 4 x 4 patch of dS summed over the tiles, the h part one per-query sum of dS per tile.
+template <int NSG, int HD, bool ROWT>
+__global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : 2)) void attn_bwd_dq_kernel(const AttnBwdParams p) {
   typedef AttHd<HD> H;
   constexpr int KS = H::KS, UT = H::UT, ROWB = H::ROWB, CHS = H::CHS, CHV = H::CHV, RPI = H::RPI, NIT = ATT_KC / H::RPI;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -77,7 +79,19 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : (NSG == 2 ? 2 : 
   float* Trow = T_lds + (wave * 16 + fr) * TLD;
   att_table_product<HD>(p.tbl, g.NT, qf, Trow, fr, fq);
   bf16x8_t tqh[NSG], tql[NSG];
-  att_slot_fragments<NSG>(g, Trow, qp.qh, qp.qw, fq, nsg, tqh, tql);
+  float wb[4][4], dwb[4][4];                                          // ROWT: w-term bias / scale of this lane's keys, and its gradient
+  float* Thq = (float*)G_lds;                                         // ROWT: [64 queries][KH] h term / scale
+  float* dThq = Thq + ATT_QT * 64;                                    // ROWT: [64 queries][KH] its gradient (one tile = one key row)
+  if (ROWT) {
+    const float inv = 1.0f / g.scale;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { wb[t][r] = Trow[g.Lh + (g.KW - 1 - (16 * t + 4 * fq + r)) + qp.qw] * inv; dwb[t][r] = 0.f; }
+    for (int j = fq; j < g.KH; j += 4) Thq[(wave * 16 + fr) * g.KH + j] = Trow[(g.KH - 1 - j) + qp.qh] * inv;
+  } else {
+    att_slot_fragments<NSG>(g, Trow, qp.qh, qp.qw, fq, nsg, tqh, tql);
+  }
   const float cs = g.scale * 1.4426950408889634f;
 
   f32x4_t dq[UT], dgt[NSG][2];
@@ -112,16 +126,18 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : (NSG == 2 ? 2 : 
       *reinterpret_cast<u32x4_t*>(K_lds + kl * ROWB + ((ch ^ kswz(kl)) << 4)) = k4;
       *reinterpret_cast<u32x4_t*>(V_lds + kl * ROWB + ((ch ^ kswz(kl)) << 4)) = v4;
     }
-    att_stage_indicator(g, G_lds, kc, Nk, nsg, tid);
+    if (!ROWT) att_stage_indicator(g, G_lds, kc, Nk, nsg, tid);
     __syncthreads();
     const int kvalid = min(ATT_KC, Nk - kc);
     if (wave_active) {
       for (int kt = 0; kt * 64 < kvalid; ++kt) {
         f32x4_t s[4], dp[4];
+        const int krow_h = (kc + kt * 64) >> 6;                        // ROWT: the key row of this tile
+        const float hb = ROWT ? Thq[(wave * 16 + fr) * g.KH + krow_h] : 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-          dp[t] = s[t];
+          s[t] = ROWT ? (f32x4_t){wb[t][0] + hb, wb[t][1] + hb, wb[t][2] + hb, wb[t][3] + hb} : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          dp[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
           const int kr = kt * 64 + 16 * t + fr;
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
@@ -131,7 +147,7 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : (NSG == 2 ? 2 : 
           }
 #pragma unroll
           for (int c = 0; c < NSG; ++c) {
-            if (c < nsg) {
+            if (!ROWT && c < nsg) {
               const bf16x8_t gf = *reinterpret_cast<const bf16x8_t*>(G_lds + c * (ATT_KC * ATT_GROW) + kr * ATT_GROW + ((fq ^ gswz(kr)) << 4));
               s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, tqh[c], s[t], 0, 0, 0);
               s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, tql[c], s[t], 0, 0, 0);
@@ -147,6 +163,16 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : (NSG == 2 ? 2 : 
             if (tail && kt * 64 + 16 * t + 4 * fq + r >= kvalid) pr = 0.f;
             s[t][r] = pr * (dp[t][r] - delta);          // dS (unscaled)
           }
+        if (ROWT) {
+          float hs = 0.f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { dwb[t][r] += s[t][r]; hs += s[t][r]; }
+          hs += __shfl_xor(hs, 16, 64);
+          hs += __shfl_xor(hs, 32, 64);
+          if (fq == 0) dThq[(wave * 16 + fr) * g.KH + krow_h] = hs;       // each key row is visited once
+        }
         // dQ^T += K^T . dS^T and dT'^T += G^T . dS^T   (key-permuted k-steps, as in the forward's P.V; the
         // transposed fragments come from the row-major images by ds_read_b64_tr_b16)
 #pragma unroll
@@ -167,7 +193,7 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : (NSG == 2 ? 2 : 
           }
 #pragma unroll
           for (int c = 0; c < NSG; ++c) {
-            if (c < nsg) {
+            if (!ROWT && c < nsg) {
 #pragma unroll
               for (int u = 0; u < 2; ++u) {
                 const unsigned char* ga = G_lds + c * (ATT_KC * ATT_GROW) + krow * ATT_GROW + (((2 * u + ((fr >> 1) & 1)) ^ gswz(krow)) << 4) + ((fr & 1) << 3);
@@ -189,6 +215,15 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : (NSG == 2 ? 2 : 
   for (int t = 0; t < g.NT / 16; ++t) *reinterpret_cast<float4*>(dTrow + 16 * t + 4 * fq) = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   // dT[q][j + qh] = dT'[q][j] (j < KH) ; dT[q][Lh + j' + qw] = dT'[q][KH + j'] : one lane per (q, slot), plain stores
+  if (ROWT) {
+    if (wave_active) {
+      for (int j = fq; j < g.KH; j += 4) dTrow[(g.KH - 1 - j) + qp.qh] = dThq[(wave * 16 + fr) * g.KH + j];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dTrow[g.Lh + (g.KW - 1 - (16 * t + 4 * fq + r)) + qp.qw] = dwb[t][r];
+    }
+  } else
 #pragma unroll
   for (int c = 0; c < NSG; ++c)
 #pragma unroll
@@ -230,7 +265,11 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : (NSG == 2 ? 2 : 
 // of 64: dV^T += dO^T.P, dK^T += scale * Q^T.dS with the P / dS accumulator tiles reused as B operands. Q and
 // dO are staged row-major only; their transposes come from ds_read_b64_tr_b16. The rel-pos bias is the
 // product T'.G^T: T' (per query, hi + lo bf16 rows staged in LDS) times this lane's key indicator (registers).
-template <int NSG, int HD>
+// ROWT (see attn_fwd_kernel): the workgroup's 64 keys are one key row; the bias of (query, key) is read from two fp32
+// LDS images of the chunk's queries, Th[q][kh] and Tw[q][kw] (row stride ATT_TS floats: conflict-free for the 4 query
+// rows x 16 key columns a wave reads at once), instead of the T'.G^T indicator product.
+#define ATT_TS 68
+template <int NSG, int HD, bool ROWT>
 __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 4 ? 2 : 3)) void attn_bwd_dkv_kernel(const AttnBwdParams p) {
   typedef AttHd<HD> H;
   constexpr int KS = H::KS, UT = H::UT, ROWB = H::ROWB, CHS = H::CHS, CHV = H::CHV, RPI = H::RPI, NIT = ATT_QT / H::RPI;
@@ -251,8 +290,11 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 4 ? 2 : 3)) void attn_bw
   float* lse_lds = (float*)(smem + 2 * ATT_QT * ROWB);           // [64] lse * log2(e); +huge for an absent query
   float* delta_lds = lse_lds + ATT_QT;                           // [64]
   unsigned char* TqH_lds = (unsigned char*)(delta_lds + ATT_QT); // [nsg][64][32 slots] bf16, hi part of T'/scale
-  unsigned char* TqL_lds = TqH_lds + nsg * ATT_QT * ATT_GROW;    // lo part
-  float* T_lds = (float*)(TqL_lds + nsg * ATT_QT * ATT_GROW);    // [64][NT+4]
+  const int tq_bytes = ROWT ? ATT_QT * ATT_TS * 4 : nsg * ATT_QT * ATT_GROW;
+  unsigned char* TqL_lds = TqH_lds + tq_bytes;                   // lo part
+  float* T_lds = (float*)(TqL_lds + tq_bytes);                   // [64][NT+4]
+  float* Thq = (float*)TqH_lds;                                  // ROWT: [64 queries][ATT_TS] h term / scale by key row
+  float* Twq = (float*)TqL_lds;                                  // ROWT: [64 queries][ATT_TS] w term / scale by key column
 
   const int64_t row_base = (int64_t)gi * T;
   const int64_t ld = 3 * (int64_t)g.D;
@@ -323,12 +365,18 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 4 ? 2 : 3)) void attn_bw
     {
       float* Trow = T_lds + (wave * 16 + fr) * TLD;
       att_table_product<HD>(p.tbl, g.NT, qfx, Trow, fr, fq);
-      bf16x8_t th[NSG], tl[NSG];
-      att_slot_fragments<NSG>(g, Trow, qw_.qh, qw_.qw, fq, nsg, th, tl);
       const int ql = wave * 16 + fr;
+      bf16x8_t th[NSG], tl[NSG];
+      if (ROWT) {
+        const float inv = 1.0f / g.scale;
+        for (int j = fq; j < g.KH; j += 4) Thq[ql * ATT_TS + j] = Trow[(g.KH - 1 - j) + qw_.qh] * inv;
+        for (int j = fq; j < g.KW; j += 4) Twq[ql * ATT_TS + j] = Trow[g.Lh + (g.KW - 1 - j) + qw_.qw] * inv;
+      } else {
+        att_slot_fragments<NSG>(g, Trow, qw_.qh, qw_.qw, fq, nsg, th, tl);
+      }
 #pragma unroll
       for (int c = 0; c < NSG; ++c) {
-        if (c < nsg) {
+        if (!ROWT && c < nsg) {
           const int off = c * (ATT_QT * ATT_GROW) + ql * ATT_GROW + ((fq ^ gswz(ql)) << 4);
           *reinterpret_cast<bf16x8_t*>(TqH_lds + off) = th[c];
           *reinterpret_cast<bf16x8_t*>(TqL_lds + off) = tl[c];
@@ -344,6 +392,11 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 4 ? 2 : 3)) void attn_bw
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
           f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = s;
+          if (ROWT) {
+            const int q0 = q32 * 32 + 16 * sub + 4 * fq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[r] = Thq[(q0 + r) * ATT_TS + kp.qh] + Twq[(q0 + r) * ATT_TS + kp.qw];
+          }
           const int qr = q32 * 32 + 16 * sub + fr;
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
@@ -353,7 +406,7 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 4 ? 2 : 3)) void attn_bw
           }
 #pragma unroll
           for (int c = 0; c < NSG; ++c) {
-            if (c < nsg) {
+            if (!ROWT && c < nsg) {
               const int off = c * (ATT_QT * ATT_GROW) + qr * ATT_GROW + ((fq ^ gswz(qr)) << 4);
               s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(TqH_lds + off), gk[c], s, 0, 0, 0);
               s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(TqL_lds + off), gk[c], s, 0, 0, 0);
@@ -401,6 +454,7 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 4 ? 2 : 3)) void attn_bw
 int attn_fill_geom(AttnGeom* g, int64_t G, int64_t Sh, int64_t Sw, int64_t heads, int64_t hd, int64_t ws,
                    int64_t Lh, int64_t Lw, int64_t NT, float scale, const char* who);
 int attn_query_tiles(const AttnGeom& g);
+bool attn_row_tiles(const AttnGeom& g);
 
 extern "C" int mfnet_attn_bwd(const void* qkv, const float* qkv_bias, const void* tbl, const void* tblT,
                               const void* out, const void* dout, const float* lse, void* dqkv, int64_t G,
@@ -415,11 +469,13 @@ extern "C" int mfnet_attn_bwd(const void* qkv, const float* qkv_bias, const void
   p.out = (const bf16_t*)out; p.dout = (const bf16_t*)dout; p.lse = lse; p.dqkv = (bf16_t*)dqkv;
   static bool attr_set = false;
   if (!attr_set) {
-    const void* fns[12] = {(const void*)attn_bwd_dq_kernel<1, 64>, (const void*)attn_bwd_dq_kernel<2, 64>, (const void*)attn_bwd_dq_kernel<4, 64>,
-                           (const void*)attn_bwd_dkv_kernel<1, 64>, (const void*)attn_bwd_dkv_kernel<2, 64>, (const void*)attn_bwd_dkv_kernel<4, 64>,
-                           (const void*)attn_bwd_dq_kernel<1, 80>, (const void*)attn_bwd_dq_kernel<2, 80>, (const void*)attn_bwd_dq_kernel<4, 80>,
-                           (const void*)attn_bwd_dkv_kernel<1, 80>, (const void*)attn_bwd_dkv_kernel<2, 80>, (const void*)attn_bwd_dkv_kernel<4, 80>};
-    for (int i = 0; i < 12; ++i) {
+    const void* fns[16] = {(const void*)attn_bwd_dq_kernel<1, 64, false>, (const void*)attn_bwd_dq_kernel<2, 64, false>, (const void*)attn_bwd_dq_kernel<4, 64, false>,
+                           (const void*)attn_bwd_dkv_kernel<1, 64, false>, (const void*)attn_bwd_dkv_kernel<2, 64, false>, (const void*)attn_bwd_dkv_kernel<4, 64, false>,
+                           (const void*)attn_bwd_dq_kernel<1, 80, false>, (const void*)attn_bwd_dq_kernel<2, 80, false>, (const void*)attn_bwd_dq_kernel<4, 80, false>,
+                           (const void*)attn_bwd_dkv_kernel<1, 80, false>, (const void*)attn_bwd_dkv_kernel<2, 80, false>, (const void*)attn_bwd_dkv_kernel<4, 80, false>,
+                           (const void*)attn_bwd_dq_kernel<4, 64, true>, (const void*)attn_bwd_dkv_kernel<4, 64, true>,
+                           (const void*)attn_bwd_dq_kernel<4, 80, true>, (const void*)attn_bwd_dkv_kernel<4, 80, true>};
+    for (int i = 0; i < 16; ++i) {
       hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) { mfnet_set_error("attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MFNET_ERR_HIP; }
     }
@@ -429,16 +485,18 @@ extern "C" int mfnet_attn_bwd(const void* qkv, const float* qkv_bias, const void
   const int rowb = hd <= 64 ? AttHd<64>::ROWB : AttHd<80>::ROWB;
   const size_t TL = (size_t)ATT_QT * (p.g.NT + 4) * 4;
   const size_t lds_dq = (size_t)att_region_a(p.g.NT, rowb) + (size_t)nsg * ATT_KC * ATT_GROW;
-  const size_t lds_dkv = 2 * (size_t)ATT_QT * rowb + 2 * ATT_QT * 4 + 2 * (size_t)nsg * ATT_QT * ATT_GROW + TL;
+  const bool rowt = attn_row_tiles(p.g);
+  const size_t lds_dkv = 2 * (size_t)ATT_QT * rowb + 2 * ATT_QT * 4 + 2 * (rowt ? (size_t)ATT_QT * ATT_TS * 4 : (size_t)nsg * ATT_QT * ATT_GROW) + TL;
   MF_CHECK_ARG(lds_dq <= 160 * 1024 && lds_dkv <= 160 * 1024, "attn_bwd: LDS demand too large");
   // the two kernels write disjoint column ranges of dqkv (q | k,v); window mode leaves nothing unwritten
   dim3 grid_q((unsigned)attn_query_tiles(p.g), (unsigned)heads, (unsigned)G);
   MF_CHECK_ARG(grid_q.z <= 65535 && grid_q.y <= 65535, "attn_bwd: grid too large");
 #define ATT_BWD(KERNEL, LDS, HDV)                                                                          \
   do {                                                                                                     \
-    if (nsg <= 1) hipLaunchKernelGGL((KERNEL<1, HDV>), grid_q, dim3(256), LDS, stream, p);                 \
-    else if (nsg == 2) hipLaunchKernelGGL((KERNEL<2, HDV>), grid_q, dim3(256), LDS, stream, p);            \
-    else hipLaunchKernelGGL((KERNEL<4, HDV>), grid_q, dim3(256), LDS, stream, p);                          \
+    if (rowt) hipLaunchKernelGGL((KERNEL<4, HDV, true>), grid_q, dim3(256), LDS, stream, p);               \
+    else if (nsg <= 1) hipLaunchKernelGGL((KERNEL<1, HDV, false>), grid_q, dim3(256), LDS, stream, p);     \
+    else if (nsg == 2) hipLaunchKernelGGL((KERNEL<2, HDV, false>), grid_q, dim3(256), LDS, stream, p);     \
+    else hipLaunchKernelGGL((KERNEL<4, HDV, false>), grid_q, dim3(256), LDS, stream, p);                   \
   } while (0)
   if (hd == 64) ATT_BWD(attn_bwd_dq_kernel, lds_dq, 64); else ATT_BWD(attn_bwd_dq_kernel, lds_dq, 80);
   MF_LAUNCH_CHECK("attn_bwd_dq");
