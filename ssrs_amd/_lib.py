@@ -42,7 +42,7 @@ _SIGS = {
     "mfnet_lora_mix_fwd": [P, P, P, P, I64, I, P],
     "mfnet_lora_mix_bwd": [P, P, P, P, P, P, I64, I, P],
     "mfnet_attn_fwd": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, F, P],
-    "mfnet_attn_bwd": [P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, F, P],
+    "mfnet_attn_bwd": [P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, F, P, I64, P],
     "mfnet_ce_loss_fwd": [P, P, P, P, P, I64, I64, I64, I64, P],
     "mfnet_ce_loss_bwd": [P, P, P, P, P, F, I64, I64, I64, I64, P],
     "mfnet_sgd_flat": [P, P, P, I64, F, F, F, F, P],
@@ -121,6 +121,8 @@ def lib():
         L.mfnet_colreduce_workspace_floats.argtypes = [c_int64, c_int64, c_int64]
         L.mfnet_gemm_tn_splits.restype = c_int64
         L.mfnet_gemm_tn_splits.argtypes = [c_int64, c_int64, c_int64]
+        L.mfnet_attn_bwd_workspace_floats.restype = c_int64
+        L.mfnet_attn_bwd_workspace_floats.argtypes = [c_int64, c_int64, c_int64, c_int64, c_int64]
         for name, sig in _SIGS.items():
             fn = getattr(L, name, None)
             if fn is None:
@@ -132,7 +134,8 @@ def lib():
 
 
 def exported_symbols():
-    return ["mfnet_version", "mfnet_last_error", "mfnet_skinny_tn_workspace_floats", "mfnet_gemm_tn_splits", "mfnet_colreduce_workspace_floats"] + list(_SIGS)
+    return ["mfnet_version", "mfnet_last_error", "mfnet_skinny_tn_workspace_floats", "mfnet_gemm_tn_splits", "mfnet_colreduce_workspace_floats",
+            "mfnet_attn_bwd_workspace_floats"] + list(_SIGS)
 
 
 def call(name: str, *args):

@@ -14,6 +14,7 @@
 //  * attn_bwd_dkv: one workgroup per 64 REAL keys (key on the lane), loops over the window's queries:
 //        dV^T += dO^T.P, dK^T += scale * Q^T.dS  with P / dS accumulator tiles reused as B operands.
 #include "attn_common.h"
+#define F4Z make_float4(0.f, 0.f, 0.f, 0.f)
 
 struct AttnBwdParams {
   AttnGeom g;
@@ -25,7 +26,9 @@ struct AttnBwdParams {
   const bf16_t* dout;     // [G*T, D]
   const float* lse;       // [G, heads, T]
   bf16_t* dqkv;           // [G*T, 3D]
+  float* bias_ws;         // ROWT: [G, heads, T, ATT_WS_LD] fp32 - per query Th[kh] / scale (KH) then Tw[kw] / scale (KW); dQ writes, dK/dV reads
 };
+#define ATT_WS_LD 128
 
 // =============================================================================================== dQ
 // Same structure as attn_fwd_kernel (attn.hip): compact (window, tile) grid, K / V row-major in LDS, rel-pos
@@ -89,6 +92,13 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : 2)) void attn_bw
 #pragma unroll
       for (int r = 0; r < 4; ++r) { wb[t][r] = Trow[g.Lh + (g.KW - 1 - (16 * t + 4 * fq + r)) + qp.qw] * inv; dwb[t][r] = 0.f; }
     for (int j = fq; j < g.KH; j += 4) Thq[(wave * 16 + fr) * g.KH + j] = Trow[(g.KH - 1 - j) + qp.qh] * inv;
+    if (qp.valid) {                   // the dK/dV kernel reads these rows instead of repeating the table product per key tile
+      float* wr = p.bias_ws + (((int64_t)gi * g.heads + head) * T + qp.tok) * ATT_WS_LD;
+      for (int j = fq; j < g.KH; j += 4) wr[j] = Trow[(g.KH - 1 - j) + qp.qh] * inv;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        *reinterpret_cast<float4*>(wr + g.KH + 16 * t + 4 * fq) = make_float4(wb[t][0], wb[t][1], wb[t][2], wb[t][3]);
+    }
   } else {
     att_slot_fragments<NSG>(g, Trow, qp.qh, qp.qw, fq, nsg, tqh, tql);
   }
@@ -342,8 +352,20 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 4 ? 2 : 3)) void attn_bw
       qok[it] = qq.valid;
     }
     const QueryPos qw_ = query_pos(g, wi, wj, qc + wave * 16 + fr);      // this wave's 16 queries: table product
+    constexpr bool from_ws = ROWT;                                        // the dQ kernel left the bias rows in global memory
     bf16x8_t qfx[KS];
-    att_load_row_frags<HD>(p.qkv + (row_base + qw_.tok) * ld + head * HD, fq, qw_.valid, qfx);
+    float4 wsv0 = F4Z, wsv1 = F4Z, wsv2 = F4Z, wsv3 = F4Z;
+    float wsh = 0.f;
+    if constexpr (from_ws) {
+      // thread -> query tid >> 2, 16 of its Tw values (4 float4) and, for the first of the four, its Th[kh of this key row]
+      const QueryPos qq = query_pos(g, wi, wj, qc + (tid >> 2));
+      const float* wr = p.bias_ws + (((int64_t)gi * g.heads + head) * T + qq.tok) * ATT_WS_LD;
+      const float4* w4 = reinterpret_cast<const float4*>(wr + g.KH + 16 * (tid & 3));
+      wsv0 = w4[0]; wsv1 = w4[1]; wsv2 = w4[2]; wsv3 = w4[3];
+      wsh = wr[kp.qh];
+    } else {
+      att_load_row_frags<HD>(p.qkv + (row_base + qw_.tok) * ld + head * HD, fq, qw_.valid, qfx);
+    }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -362,21 +384,20 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 4 ? 2 : 3)) void attn_bw
         lse_lds[ql] = qok[it] ? lsev[it] * 1.4426950408889634f : 1e30f;     // absent query: P = exp2(-huge) = 0
       }
     }
-    {
+    if constexpr (from_ws) {
+      const int ql = tid >> 2;
+      float4* w4 = reinterpret_cast<float4*>(Twq + ql * ATT_TS + 16 * (tid & 3));
+      w4[0] = wsv0; w4[1] = wsv1; w4[2] = wsv2; w4[3] = wsv3;
+      if ((tid & 3) == 0) Thq[ql * ATT_TS + kp.qh] = wsh;
+    } else {
       float* Trow = T_lds + (wave * 16 + fr) * TLD;
       att_table_product<HD>(p.tbl, g.NT, qfx, Trow, fr, fq);
       const int ql = wave * 16 + fr;
       bf16x8_t th[NSG], tl[NSG];
-      if (ROWT) {
-        const float inv = 1.0f / g.scale;
-        for (int j = fq; j < g.KH; j += 4) Thq[ql * ATT_TS + j] = Trow[(g.KH - 1 - j) + qw_.qh] * inv;
-        for (int j = fq; j < g.KW; j += 4) Twq[ql * ATT_TS + j] = Trow[g.Lh + (g.KW - 1 - j) + qw_.qw] * inv;
-      } else {
-        att_slot_fragments<NSG>(g, Trow, qw_.qh, qw_.qw, fq, nsg, th, tl);
-      }
+      att_slot_fragments<NSG>(g, Trow, qw_.qh, qw_.qw, fq, nsg, th, tl);
 #pragma unroll
       for (int c = 0; c < NSG; ++c) {
-        if (!ROWT && c < nsg) {
+        if (c < nsg) {
           const int off = c * (ATT_QT * ATT_GROW) + ql * ATT_GROW + ((fq ^ gswz(ql)) << 4);
           *reinterpret_cast<bf16x8_t*>(TqH_lds + off) = th[c];
           *reinterpret_cast<bf16x8_t*>(TqL_lds + off) = tl[c];
@@ -456,10 +477,20 @@ int attn_fill_geom(AttnGeom* g, int64_t G, int64_t Sh, int64_t Sw, int64_t heads
 int attn_query_tiles(const AttnGeom& g);
 bool attn_row_tiles(const AttnGeom& g);
 
+// floats of optional scratch for mfnet_attn_bwd: non-zero only for global attention over 64-wide key rows, where the dQ
+// kernel hands each query's bias rows (Th, Tw) to the dK/dV kernel through it
+extern "C" int64_t mfnet_attn_bwd_workspace_floats(int64_t G, int64_t Sh, int64_t Sw, int64_t heads, int64_t ws) {
+  if (G <= 0 || Sh <= 0 || Sw <= 0 || heads <= 0) return 0;
+  AttnGeom g{};
+  g.ws = (int)ws; g.KW = ws > 0 ? (int)ws : (int)Sw; g.KH = ws > 0 ? (int)ws : (int)Sh;
+  return attn_row_tiles(g) ? G * heads * Sh * Sw * ATT_WS_LD : 0;
+}
+
 extern "C" int mfnet_attn_bwd(const void* qkv, const float* qkv_bias, const void* tbl, const void* tblT,
                               const void* out, const void* dout, const float* lse, void* dqkv, int64_t G,
                               int64_t Sh, int64_t Sw, int64_t heads, int64_t hd, int64_t ws, int64_t Lh,
-                              int64_t Lw, int64_t NT, float scale, hipStream_t stream) {
+                              int64_t Lw, int64_t NT, float scale, float* workspace, int64_t workspace_floats,
+                              hipStream_t stream) {
   MF_CHECK_ARG(qkv && qkv_bias && tbl && tblT && out && dout && lse && dqkv, "attn_bwd: null pointer");
   AttnBwdParams p;
   int rc = attn_fill_geom(&p.g, G, Sh, Sw, heads, hd, ws, Lh, Lw, NT, scale, "attn_bwd");
@@ -485,8 +516,14 @@ extern "C" int mfnet_attn_bwd(const void* qkv, const float* qkv_bias, const void
   const int rowb = hd <= 64 ? AttHd<64>::ROWB : AttHd<80>::ROWB;
   const size_t TL = (size_t)ATT_QT * (p.g.NT + 4) * 4;
   const size_t lds_dq = (size_t)att_region_a(p.g.NT, rowb) + (size_t)nsg * ATT_KC * ATT_GROW;
-  const bool rowt = attn_row_tiles(p.g);
-  const size_t lds_dkv = 2 * (size_t)ATT_QT * rowb + 2 * ATT_QT * 4 + 2 * (rowt ? (size_t)ATT_QT * ATT_TS * 4 : (size_t)nsg * ATT_QT * ATT_GROW) + TL;
+  const bool rowt = attn_row_tiles(p.g) && workspace != nullptr;      // without the scratch the general kernels run
+  p.bias_ws = nullptr;
+  if (rowt) {
+    MF_CHECK_ARG(workspace_floats >= G * heads * Sh * Sw * ATT_WS_LD, "attn_bwd: workspace too small (mfnet_attn_bwd_workspace_floats)");
+    p.bias_ws = workspace;
+  }
+  const size_t lds_dkv = 2 * (size_t)ATT_QT * rowb + 2 * ATT_QT * 4 + 2 * (rowt ? (size_t)ATT_QT * ATT_TS * 4 : (size_t)nsg * ATT_QT * ATT_GROW) +
+                         (p.bias_ws ? 0 : TL);
   MF_CHECK_ARG(lds_dq <= 160 * 1024 && lds_dkv <= 160 * 1024, "attn_bwd: LDS demand too large");
   // the two kernels write disjoint column ranges of dqkv (q | k,v); window mode leaves nothing unwritten
   dim3 grid_q((unsigned)attn_query_tiles(p.g), (unsigned)heads, (unsigned)G);

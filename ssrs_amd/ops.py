@@ -320,9 +320,11 @@ def attn_bwd(qkv, qkv_bias, tbl, tblT, out, dout, lse, G, Sh, Sw, heads, ws, Lh,
     hd = D // heads
     assert dout.is_contiguous() and dout.dtype == torch.bfloat16
     dqkv = torch.empty_like(qkv)
+    nws = int(_lib.lib().mfnet_attn_bwd_workspace_floats(G, Sh, Sw, heads, ws))
+    wsp = torch.empty(nws, dtype=torch.float32, device=qkv.device) if nws else None
     call("mfnet_attn_bwd", qkv.data_ptr(), qkv_bias.data_ptr(), tbl.data_ptr(), tblT.data_ptr(), out.data_ptr(),
          dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), G, Sh, Sw, heads, hd, ws, Lh, Lw, tbl.shape[0],
-         float(scale), _stream(qkv))
+         float(scale), _p(wsp), nws, _stream(qkv))
     return dqkv
 
 
