@@ -235,7 +235,10 @@ static size_t attn_fwd_lds(const AttnGeom& g, int rowb) {
 }
 
 // global attention whose key rows are exactly one 64-key tile wide: the separable-bias (ROWT) kernels apply
-bool attn_row_tiles(const AttnGeom& g) { return g.ws == 0 && g.KW == 64 && g.KH <= 64 && getenv("MFNET_ATTN_NO_ROWT") == nullptr; }
+bool attn_row_tiles(const AttnGeom& g) {
+  static const bool off = getenv("MFNET_ATTN_NO_ROWT") != nullptr;      // A/B aid: the general (indicator product) kernels
+  return !off && g.ws == 0 && g.KW == 64 && g.KH <= 64;
+}
 
 // number of (window, 64-query tile) pairs of one image = grid.x of the query-tiled kernels
 int attn_query_tiles(const AttnGeom& g) {
