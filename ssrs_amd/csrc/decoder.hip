@@ -118,7 +118,8 @@ __device__ __forceinline__ void colreduce_finish(const ColRedParams& p, const in
   for (int c0 = 0; c0 < ncg; c0 += cpp) {
     const int cl = threadIdx.x % cpp, part = threadIdx.x / cpp, c4 = c0 + cl;
     float4 tot = F4ZERO;
-    for (int sb = part; sb < splits; sb += 16 * parts) {
+    const bool on = part < parts;                      // 256 % cpp != 0: the threads past the last whole part idle
+    for (int sb = part; on && sb < splits; sb += 16 * parts) {
       float4 v[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
@@ -129,7 +130,7 @@ __device__ __forceinline__ void colreduce_finish(const ColRedParams& p, const in
       for (int k = 0; k < 16; ++k) tot = f4add(tot, v[k]);
     }
     __syncthreads();
-    red0[part * cpp + cl] = tot;
+    if (on) red0[part * cpp + cl] = tot;
     __syncthreads();
     if (part == 0) {
       for (int k = 1; k < parts; ++k) tot = f4add(tot, red0[k * cpp + cl]);
@@ -257,11 +258,11 @@ static int64_t colreduce_splits(int64_t G, int64_t P, int C, int64_t* rpb_out) {
 }
 // floats of workspace for one column reduction over G groups of P rows x C columns (partial slabs)
 extern "C" int64_t mfnet_colreduce_workspace_floats(int64_t G, int64_t P, int64_t C) {
-  if (G <= 0 || P <= 0 || C <= 0 || C % 4 || C > 1024 || 256 % (C / 4)) return 0;
+  if (G <= 0 || P <= 0 || C <= 0 || C % 4 || C > 1024) return 0;
   return G * colreduce_splits(G, P, (int)C, nullptr) * 2 * C;
 }
 static int launch_colreduce(ColRedParams& p, int64_t G, float* workspace, unsigned int* counters, hipStream_t stream, const char* who) {
-  MF_CHECK_ARG(p.C > 0 && p.C % 4 == 0 && p.C <= 1024 && 256 % (p.C / 4) == 0, "%s: C=%d must be a multiple of 4 dividing 1024", who, p.C);
+  MF_CHECK_ARG(p.C > 0 && p.C % 4 == 0 && p.C <= 1024, "%s: C=%d must be a multiple of 4, at most 1024", who, p.C);
   MF_CHECK_ARG(G > 0 && G < 65536 && p.P > 0, "%s: bad group geometry", who);
   MF_CHECK_ARG(workspace && counters, "%s: needs a workspace of mfnet_colreduce_workspace_floats(G, P, C) floats and G zeroed tickets", who);
   int64_t rpb;

@@ -413,7 +413,7 @@ extern "C" int64_t mfnet_gemm_tn_splits(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 1;
   const int64_t tiles = ceil_div64(N, 64) * ceil_div64(K, 256);
   int64_t s = ceil_div64(768, tiles);                  // ~3 workgroups per CU
-  const int64_t smax = ceil_div64(M, 512);             // at least 16 steps of 32 rows per split (partials cost traffic too)
+  const int64_t smax = ceil_div64(M, 256);             // at least 8 steps of 32 rows per split (partials cost traffic too)
   if (s > smax) s = smax;
   if (s > 256) s = 256;
   return s < 1 ? 1 : s;

@@ -69,7 +69,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, want_f32=True, want_bf16=
         assert dres.is_contiguous() and dres.dtype == torch.float32
     # weight gradients: one deterministic column reduction when the rows are dense (the dx kernel's own path adds
     # them with float atomics from every wave)
-    split_w = (dgamma is not None and lddy == C and ldx == C and C % 4 == 0 and C <= 1024 and 256 % (C // 4) == 0
+    split_w = (dgamma is not None and lddy == C and ldx == C and C % 4 == 0 and C <= 1024
                and dy2.is_contiguous() and x2.is_contiguous())
     call("mfnet_layernorm_bwd", dy2.data_ptr(), _DT[dy.dtype], lddy, x2.data_ptr(), _DT[x.dtype], ldx,
          mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), _p(dres), _p(dx), _p(dxb), C,
@@ -411,7 +411,7 @@ def adapter_mix_bwd(dh, ada, wx, wy):
 def bias_grad(dy, out=None):
     _chk(dy)
     dy2, M, N, ld = _rows2d(dy)
-    if out is None and ld == N and N % 4 == 0 and N <= 1024 and 256 % (N // 4) == 0 and dy2.is_contiguous():
+    if out is None and ld == N and N % 4 == 0 and N <= 1024 and dy2.is_contiguous():
         # the deterministic column reduction (16-byte loads for bf16), no float atomics
         return colsum(dy2, 1, M)[0].view(N)
     if out is None:

@@ -379,8 +379,8 @@ def test_split_sums_are_folded_into_the_gather(ops):
 
 @pytest.mark.parametrize("M,N", [(4096, 768), (4096, 192), (16384, 256), (65536, 64), (1000, 3072), (77, 1280)])
 def test_bias_grad(ops, M, N):
-    """column sums of a bf16 gradient: widths that take the deterministic reduction (N/4 divides 256) and widths that take
-    the atomic kernel (768, 192, 3072, 1280 - the ViT adapters' and MLPs')."""
+    """column sums of a bf16 gradient: widths that take the deterministic reduction (multiples of 4 up to 1024, the ViT
+    adapters' 192 / 768 included) and widths that take the atomic kernel (3072, 1280)."""
     dy = rnd(M, N, seed=11).to(torch.bfloat16)
     out = ops.bias_grad(dy)
     assert tuple(out.shape) == (N,)
@@ -389,7 +389,9 @@ def test_bias_grad(ops, M, N):
 
 # ------------------------------------------------------------------------------------------ column reductions
 @pytest.mark.parametrize("G,P,C,dt", [(1, 65536, 64, torch.float32), (1, 16384, 256, torch.bfloat16), (16, 4096, 64, torch.float32),
-                                      (3, 777, 256, torch.float32), (1, 100, 1024, torch.float32), (2, 9, 8, torch.bfloat16)])
+                                      (3, 777, 256, torch.float32), (1, 100, 1024, torch.float32), (2, 9, 8, torch.bfloat16),
+                                      (1, 4096, 768, torch.bfloat16), (2, 500, 192, torch.float32), (1, 300, 1000, torch.float32),
+                                      (1, 2048, 192, torch.bfloat16), (1, 64, 12, torch.float32)])   # widths whose quarter does not divide 256
 def test_colsum_coldot_deterministic(ops, G, P, C, dt):
     """BatchNorm statistics / SE pools: values against float64, and bit-identical results run after run (the
     finish is a fixed-order sum of per-workgroup slabs, not float atomics)."""
