@@ -72,6 +72,15 @@ int mfnet_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int6
                     int64_t rows_per_group, int n_groups, int R, float lr_scale, int act, const void* aux,
                     int64_t ldaux, void* out_pre, int64_t ldpre, const float* residual, int64_t ldres,
                     int64_t res_row_mod, void* out, int out_dtype, int64_t ldc, int k_splits, hipStream_t stream);
+/* The same GEMM with per-group weights: rows [g*rows_per_group, (g+1)*rows_per_group) (g cyclic over n_groups) use
+ * W + g*w_group_stride and bias + g*bias_group_stride (elements; multiples of 8 / 4). One launch for the per-modality
+ * dense layers of the MMAdapter block - Img_Adapter / DSM_Adapter and MLPx_ / MLPy_Adapter, adapter.py:16-25 applied at
+ * adapter_fusionblock.py:88-108 - instead of two half-batch GEMMs. No low-rank term, no split-K. */
+int mfnet_gemm_bf16_grouped(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t w_group_stride, int64_t M,
+                            int64_t N, int64_t K, const float* bias, int64_t bias_group_stride, int64_t rows_per_group,
+                            int n_groups, int act, const void* aux, int64_t ldaux, void* out_pre, int64_t ldpre,
+                            const float* residual, int64_t ldres, void* out, int out_dtype, int64_t ldc,
+                            hipStream_t stream);
 
 /* ---- skinny products of the low-rank paths (layers.py:149-165,244-268 forward "x @ A^T" and the
  * wgrads of lora_A / lora_B). nt (MFMA): out[m,j] = scale * sum_k X[m,k] Wt[g(m)][j,k], X bf16 [M,K], Wt fp32

@@ -40,6 +40,7 @@ struct GemmParams {
   void* out; int out_dtype; int64_t ldc;
   int tiles_m, tiles_n;
   int k_splits;                         // > 1: blockIdx.y owns a K range and stores its fp32 partial into slice blockIdx.y of out
+  int64_t w_group_stride, bias_group_stride;   // != 0: W / bias of row group g start g * stride elements further (per-modality layers)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -69,6 +70,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
   }
   const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
+  // modality group of this row tile (uniform per workgroup: the host splits launches that would straddle)
+  const int grp = p.n_groups > 1 ? (int)(((unsigned)m0 / (unsigned)p.rows_per_group) % (unsigned)p.n_groups) : 0;
+  const bf16_t* Wg = p.W + (int64_t)grp * p.w_group_stride;
+  const float* biasg = p.bias ? p.bias + (int64_t)grp * p.bias_group_stride : nullptr;
 
   // ---- staging addresses: this wave fills rows [wave*32, wave*32+32) of both tiles, 8 rows/instr
   const int srow = lane >> 3;        // 0..7 within an 8-row group
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 #endif
     const int ca = sch ^ swz_x(row), cw = sch ^ swz_w(row);
     a_src[i] = p.A + (int64_t)gm * p.lda + (ca << 3);
-    w_src[i] = p.W + (int64_t)gn * p.ldw + (cw << 3);
+    w_src[i] = Wg + (int64_t)gn * p.ldw + (cw << 3);
     a_tail[i] = (half_tail && ca >= 4) ? -32 : 0;
     w_tail[i] = (half_tail && cw >= 4) ? -32 : 0;
   }
@@ -137,10 +142,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     mok[mi] = mrow[mi] < p.M;
   }
   float4 bias4[4];
-  if (p.bias) {
+  if (biasg) {
     const int nbc = nb < p.N ? nb : p.N - 16;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) bias4[ni] = *reinterpret_cast<const float4*>(p.bias + nbc + 4 * ni);
+    for (int ni = 0; ni < 4; ++ni) bias4[ni] = *reinterpret_cast<const float4*>(biasg + nbc + 4 * ni);
   }
   // Low-rank update = extra MFMA k-steps whose 32 k-slots hold the rank index up to three times:
   // slots [0,Rp) U_hi.V_hi, [Rp,2Rp) U_lo.V_hi, [2Rp,3Rp) U_hi.V_lo (hi = bf16(x), lo = bf16(x - hi); Rp = 8
@@ -157,8 +162,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
       dst[0] = *reinterpret_cast<const float4*>(src + lk0);
       dst[1] = *reinterpret_cast<const float4*>(src + lk1);
     };
-    const int g = p.n_groups > 1 ? (int)(((unsigned)m0 / (unsigned)p.rows_per_group) % (unsigned)p.n_groups) : 0;
-    const float* vg = p.V + (int64_t)g * p.v_group_stride;
+    const float* vg = p.V + (int64_t)grp * p.v_group_stride;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) load_raw(uraw[mi], p.U + (int64_t)(mok[mi] ? mrow[mi] : p.M - 1) * p.ldu);
 #pragma unroll
@@ -353,12 +357,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
   }
 }
 
-extern "C" int mfnet_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int64_t N,
-                               int64_t K, const float* bias, const float* U, int64_t ldu, const float* V,
-                               int64_t v_group_stride, int64_t rows_per_group, int n_groups, int R,
-                               float lr_scale, int act, const void* aux, int64_t ldaux, void* out_pre,
-                               int64_t ldpre, const float* residual, int64_t ldres, int64_t res_row_mod,
-                               void* out, int out_dtype, int64_t ldc, int k_splits, hipStream_t stream) {
+static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t w_group_stride, int64_t M, int64_t N,
+                     int64_t K, const float* bias, int64_t bias_group_stride, const float* U, int64_t ldu, const float* V,
+                     int64_t v_group_stride, int64_t rows_per_group, int n_groups, int R,
+                     float lr_scale, int act, const void* aux, int64_t ldaux, void* out_pre,
+                     int64_t ldpre, const float* residual, int64_t ldres, int64_t res_row_mod,
+                     void* out, int out_dtype, int64_t ldc, int k_splits, hipStream_t stream) {
   MF_CHECK_ARG(A && W && out, "gemm_bf16: null operand");
   MF_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm_bf16: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   MF_CHECK_ARG(K % 32 == 0, "gemm_bf16: K=%lld must be a multiple of 32", (long long)K);
@@ -371,24 +375,28 @@ extern "C" int mfnet_gemm_bf16(const void* A, int64_t lda, const void* W, int64_
   MF_CHECK_ARG((act != 2 && act != 4) || (aux && ldaux >= N && ldaux % 8 == 0), "gemm_bf16: act=2/4 needs aux");
   MF_CHECK_ARG(!out_pre || (act != 2 && act != 4 && ldpre >= N && ldpre % 8 == 0), "gemm_bf16: bad out_pre");
   MF_CHECK_ARG(!residual || (ldres >= N && ldres % 4 == 0), "gemm_bf16: bad residual ld");
-  if (U) {
-    MF_CHECK_ARG(V && R > 0 && R <= GEMM_MAX_R && R % 4 == 0 && ldu >= R && ldu % 4 == 0, "gemm_bf16: bad low-rank args (R=%d)", R);
-    MF_CHECK_ARG(n_groups >= 1 && (n_groups == 1 || rows_per_group >= 16), "gemm_bf16: bad group args (rows_per_group must be >= 16)");
-  }
+  if (U) MF_CHECK_ARG(V && R > 0 && R <= GEMM_MAX_R && R % 4 == 0 && ldu >= R && ldu % 4 == 0, "gemm_bf16: bad low-rank args (R=%d)", R);
+  const bool grouped = U || w_group_stride != 0 || bias_group_stride != 0;
+  if (grouped) MF_CHECK_ARG(n_groups >= 1 && (n_groups == 1 || rows_per_group >= 16), "gemm_bf16: bad group args (rows_per_group must be >= 16)");
+  if (!grouped) n_groups = 1;
+  MF_CHECK_ARG(w_group_stride % 8 == 0 && bias_group_stride % 4 == 0 && w_group_stride >= 0 && bias_group_stride >= 0, "gemm_bf16: group strides of W / bias must be multiples of 8 / 4 elements");
+  MF_CHECK_ARG(k_splits == 1 || (w_group_stride == 0 && bias_group_stride == 0), "gemm_bf16: split-K takes no grouped weights");
   MF_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31), "gemm_bf16: shape too large");
   MF_CHECK_ARG(k_splits >= 1 && k_splits <= 1024, "gemm_bf16: bad k_splits");
   MF_CHECK_ARG(k_splits == 1 || (out_dtype == MFNET_F32 && !bias && !U && act == 0 && !out_pre && !residual),
                "gemm_bf16: split-K supports only the plain fp32 accumulate-into-out epilogue");
   if (M == 0) return MFNET_OK;
-  if (U && n_groups > 1 && rows_per_group % BM != 0) {
+  if (grouped && n_groups > 1 && rows_per_group % BM != 0) {
     // The kernel takes the modality group per 128-row tile. Row blocks that do not end on a tile boundary
     // are launched one by one (never the case for MFNet's 256-pixel tiles: rows_per_group = B * 256).
     MF_CHECK_ARG(res_row_mod == 0, "gemm_bf16: grouped low-rank update with rows_per_group %% 128 != 0 cannot take res_row_mod");
     const size_t osz = out_dtype == MFNET_BF16 ? 2 : 4;
     for (int64_t r0 = 0, b = 0; r0 < M; r0 += rows_per_group, ++b) {
       const int64_t rows = M - r0 < rows_per_group ? M - r0 : rows_per_group;
-      const int rc = mfnet_gemm_bf16((const char*)A + r0 * lda * 2, lda, W, ldw, rows, N, K, bias, U + r0 * ldu, ldu,
-                                     V + (b % n_groups) * v_group_stride, 0, 0, 1, R, lr_scale, act,
+      const int gsel = (int)(b % n_groups);
+      const int rc = gemm_impl((const char*)A + r0 * lda * 2, lda, (const char*)W + gsel * w_group_stride * 2, ldw, 0, rows, N, K,
+                                     bias ? bias + gsel * bias_group_stride : nullptr, 0, U ? U + r0 * ldu : nullptr, ldu,
+                                     V ? V + gsel * v_group_stride : nullptr, 0, 0, 1, R, lr_scale, act,
                                      aux ? (const char*)aux + r0 * ldaux * 2 : nullptr, ldaux,
                                      out_pre ? (char*)out_pre + r0 * ldpre * 2 : nullptr, ldpre,
                                      residual ? residual + r0 * ldres : nullptr, ldres, 0,
@@ -409,6 +417,7 @@ extern "C" int mfnet_gemm_bf16(const void* A, int64_t lda, const void* W, int64_
   const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
   MF_CHECK_ARG(nwg < (1ll << 31), "gemm_bf16: too many tiles");
   p.k_splits = k_splits;
+  p.w_group_stride = w_group_stride; p.bias_group_stride = bias_group_stride;
   const dim3 grid((unsigned)nwg, (unsigned)k_splits);
 #define MF_GEMM_LAUNCH(A_, L_) hipLaunchKernelGGL((gemm_bf16_kernel<A_, L_>), grid, dim3(256), 0, stream, p)
 #define MF_GEMM_CASE(A_) case A_: if (U) MF_GEMM_LAUNCH(A_, true); else MF_GEMM_LAUNCH(A_, false); break;
@@ -417,4 +426,27 @@ extern "C" int mfnet_gemm_bf16(const void* A, int64_t lda, const void* W, int64_
 #undef MF_GEMM_LAUNCH
   MF_LAUNCH_CHECK("gemm_bf16");
   return MFNET_OK;
+}
+
+extern "C" int mfnet_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int64_t N,
+                               int64_t K, const float* bias, const float* U, int64_t ldu, const float* V,
+                               int64_t v_group_stride, int64_t rows_per_group, int n_groups, int R,
+                               float lr_scale, int act, const void* aux, int64_t ldaux, void* out_pre,
+                               int64_t ldpre, const float* residual, int64_t ldres, int64_t res_row_mod,
+                               void* out, int out_dtype, int64_t ldc, int k_splits, hipStream_t stream) {
+  return gemm_impl(A, lda, W, ldw, 0, M, N, K, bias, 0, U, ldu, V, v_group_stride, rows_per_group, n_groups, R, lr_scale, act, aux, ldaux,
+                   out_pre, ldpre, residual, ldres, res_row_mod, out, out_dtype, ldc, k_splits, stream);
+}
+
+// Per-modality dense layers in one launch: rows [g*rows_per_group, (g+1)*rows_per_group) (cyclically over n_groups) multiply
+// W + g*w_group_stride and add bias + g*bias_group_stride - the Img_ / DSM_ and MLPx_ / MLPy_ adapters of the MMAdapter
+// block, whose two half-batch GEMMs of 32-64 tiles each would leave most of the chip idle (adapter_fusionblock.py:88-108).
+extern "C" int mfnet_gemm_bf16_grouped(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t w_group_stride, int64_t M,
+                                       int64_t N, int64_t K, const float* bias, int64_t bias_group_stride, int64_t rows_per_group,
+                                       int n_groups, int act, const void* aux, int64_t ldaux, void* out_pre, int64_t ldpre,
+                                       const float* residual, int64_t ldres, void* out, int out_dtype, int64_t ldc,
+                                       hipStream_t stream) {
+  MF_CHECK_ARG(n_groups >= 1 && rows_per_group > 0, "gemm_bf16_grouped: bad group args");
+  return gemm_impl(A, lda, W, ldw, w_group_stride, M, N, K, bias, bias_group_stride, nullptr, 0, nullptr, 0, rows_per_group, n_groups, 0,
+                   1.0f, act, aux, ldaux, out_pre, ldpre, residual, ldres, 0, out, out_dtype, ldc, 1, stream);
 }

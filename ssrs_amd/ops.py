@@ -165,6 +165,31 @@ def gemm(a, w, *, bias=None, U=None, V=None, rows_per_group=0, n_groups=1, lr_sc
     return (out, pre) if want_pre else out
 
 
+def gemm_grouped(a, w, *, bias=None, rows_per_group, act=0, aux=None, want_pre=False, residual=None, out=None,
+                 out_dtype=torch.bfloat16):
+    """Per-group weights: a [M,K] bf16, w [G,N,K] bf16, bias [G,N] fp32 | None; rows [g*rpg, (g+1)*rpg) use w[g], bias[g]
+    (the per-modality adapters in one launch). Otherwise as gemm (no low-rank term)."""
+    _chk(a, w, bias, aux, residual, out)
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.dim() == 3 and w.is_contiguous()
+    a2, M, K, lda = _rows2d(a)
+    G, N, K2 = w.shape
+    assert K2 == K and (bias is None or (bias.is_contiguous() and tuple(bias.shape) == (G, N)))
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    assert out.stride(-1) == 1
+    pre = torch.empty((M, N), dtype=torch.bfloat16, device=a.device) if want_pre else None
+    if GEMM_TRACE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(a.device))
+    call("mfnet_gemm_bf16_grouped", a2.data_ptr(), lda, w.data_ptr(), K, N * K, M, N, K, _p(bias), N if bias is not None else 0,
+         rows_per_group, G, act, _p(aux), aux.stride(-2) if aux is not None else 0, _p(pre), N if pre is not None else 0,
+         _p(residual), residual.stride(-2) if residual is not None else 0, out.data_ptr(), _DT[out.dtype], out.stride(-2), _stream(a))
+    if GEMM_TRACE is not None:
+        ev1.record(torch.cuda.current_stream(a.device))
+        GEMM_TRACE.append((ev0, ev1, 2.0 * M * N * K, (M, N, K)))
+    return (out, pre) if want_pre else out
+
+
 def skinny_nt(x, wt, scale=1.0, out=None, rows_per_group=0):
     """out[m, j] = scale * sum_k x[m,k] wt[g(m)][j,k]; x bf16 [M,K]; wt fp32 [R,K] or [G,R,K] with
     g(m) = m // rows_per_group (per-modality matrices) -> fp32 [M, R] (row stride a multiple of 4)."""

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .bank import deliver, weight_bf16
+from .bank import deliver, derived, weight_bf16
 from .vit import BF, Adapter, _attention, _geom, w_bf16, wT_bf16
 
 
@@ -42,20 +42,35 @@ class MLPBlock(nn.Module):
         self.act = act()
 
 
-# ---- trainable dense layer on a row range: forward + (dgrad, wgrad, bias grad) -------------------
-def _dense_fwd(x_bf, W, b, act=False, residual=None, out=None, out_dtype=BF):
-    wb = weight_bf16(W)
+# ---- trainable per-modality dense layer pair (x rows use (Wx, bx), y rows (Wy, by)): forward + (dgrad, wgrad, bias grad)
+def _w2(Wx, Wy, transpose=False):
+    """bf16 [2, N, K] GEMM image of the two modalities' weights (or of their transposes), kept per step by the bank."""
+    a, b = Wx.detach(), Wy.detach()
+    if transpose:
+        a, b = a.t(), b.t()
+    return derived(("w2", transpose, a.data_ptr(), b.data_ptr()), (2,) + tuple(a.shape), BF, lambda t: [(t[0], a), (t[1], b)], device=a.device)
+
+
+def _b2(bx, by):
+    a, b = bx.detach(), by.detach()
+    return derived(("b2", a.data_ptr(), b.data_ptr()), (2, a.shape[0]), torch.float32, lambda t: [(t[0], a), (t[1], b)], device=a.device)
+
+
+def _dense_fwd(x_bf, Wx, bx, Wy, by, half, act=False, residual=None, out=None, out_dtype=BF):
+    """one grouped launch for both modalities (adapter.py:16-25 with Img_ / DSM_ or MLPx_ / MLPy_ weights)"""
     if act:
-        return ops.gemm(x_bf, wb, bias=b, act=1, want_pre=True)
-    return ops.gemm(x_bf, wb, bias=b, residual=residual, out=out, out_dtype=out_dtype)
+        return ops.gemm_grouped(x_bf, _w2(Wx, Wy), bias=_b2(bx, by), rows_per_group=half, act=1, want_pre=True)
+    return ops.gemm_grouped(x_bf, _w2(Wx, Wy), bias=_b2(bx, by), rows_per_group=half, residual=residual, out=out, out_dtype=out_dtype)
 
 
-def _dense_bwd(d_bf, x_bf, W, gelu_aux=None):
-    """-> (dx bf16, dW fp32, db fp32) for y = x W^T + b."""
-    wT = weight_bf16(W.t())
-    dx = ops.gemm(d_bf, wT, act=2 if gelu_aux is not None else 0, aux=gelu_aux)
-    dW = ops.gemm_tn(d_bf, x_bf, lazy=True)          # summed over its splits by the gradient delivery
-    db = ops.bias_grad(d_bf)
+def _dense_bwd(d_bf, x_bf, Wx, Wy, half, gelu_aux=None):
+    """-> (dx bf16 for both halves, (dWx, dWy) fp32 split sums, (dbx, dby) fp32) for y = x W_g^T + b_g."""
+    dx = ops.gemm_grouped(d_bf, _w2(Wx, Wy, transpose=True), rows_per_group=half, act=2 if gelu_aux is not None else 0, aux=gelu_aux)
+    dW = [ops.gemm_tn(d_bf[sl], x_bf[sl], lazy=True) for sl in (slice(0, half), slice(half, 2 * half))]   # summed by the delivery
+    if d_bf.is_contiguous() and d_bf.shape[1] % 4 == 0 and d_bf.shape[1] <= 1024:
+        db = ops.colsum(d_bf, 2, half)[0]                                                                  # [2, N], deterministic
+    else:
+        db = [ops.bias_grad(d_bf[:half]), ops.bias_grad(d_bf[half:])]
     return dx, dW, db
 
 
@@ -77,20 +92,16 @@ class _AdapterAttnBranch(torch.autograd.Function):
         # proj: bf16 copy of o_proj (adapter input) + fp32 h + o_proj
         hm = torch.empty_like(h2)
         _, op = ops.gemm(o, w_bf16(attn.proj.weight), bias=attn.proj.bias, residual=h2, out=hm, want_pre=True)
-        acts, pres = [], []
-        for sl, (w1, b1, w2, b2) in ((slice(0, half), (w1x, b1x, w2x, b2x)), (slice(half, M), (w1y, b1y, w2y, b2y))):
-            a, p = _dense_fwd(op[sl], w1, b1, act=True)
-            _dense_fwd(a, w2, b2, residual=hm[sl], out=hm[sl])
-            acts.append(a)
-            pres.append(p)
-        ctx.save_for_backward(h2, mean, rstd, qkv, o, lse, op, acts[0], acts[1], pres[0], pres[1], w1x, w2x, w1y, w2y)
+        a, p = _dense_fwd(op, w1x, b1x, w1y, b1y, half, act=True)
+        _dense_fwd(a, w2x, b2x, w2y, b2y, half, residual=hm, out=hm)
+        ctx.save_for_backward(h2, mean, rstd, qkv, o, lse, op, a, p, w1x, w2x, w1y, w2y)
         ctx.blk, ctx.geom, ctx.tb = blk, geom, tb
         ctx.params = (w1x, b1x, w2x, b2x, w1y, b1y, w2y, b2y)
         return hm.view(h.shape)
 
     @staticmethod
     def backward(ctx, dout):
-        (h2, mean, rstd, qkv, o, lse, op, ax, ay, px, py, w1x, w2x, w1y, w2y) = ctx.saved_tensors
+        (h2, mean, rstd, qkv, o, lse, op, a, p, w1x, w2x, w1y, w2y) = ctx.saved_tensors
         blk, (B, Sh, Sw, heads, ws), (tbl, tblT, Lh, Lw) = ctx.blk, ctx.geom, ctx.tb
         attn = blk.attn
         M, D = h2.shape
@@ -99,12 +110,10 @@ class _AdapterAttnBranch(torch.autograd.Function):
         d2 = dout.reshape(M, D).contiguous()
         d_bf = ops.cast(d2, BF)
         dop = torch.empty_like(d_bf)
-        grads = []
-        for sl, a, p, w1, w2 in ((slice(0, half), ax, px, w1x, w2x), (slice(half, M), ay, py, w1y, w2y)):
-            dpre, dW2, db2 = _dense_bwd(d_bf[sl], a, w2, gelu_aux=p)
-            dxo, dW1, db1 = _dense_bwd(dpre, op[sl], w1)
-            ops.add_bf16(dxo, d_bf[sl], dop[sl])               # adapter skip: d o_proj = d + fc1-path
-            grads += [dW1, db1, dW2, db2]
+        dpre, dW2, db2 = _dense_bwd(d_bf, a, w2x, w2y, half, gelu_aux=p)
+        dxo, dW1, db1 = _dense_bwd(dpre, op, w1x, w1y, half)
+        ops.add_bf16(dxo, d_bf, dop)                           # adapter skip: d o_proj = d + fc1-path
+        grads = [dW1[0], db1[0], dW2[0], db2[0], dW1[1], db1[1], dW2[1], db2[1]]
         dO = ops.gemm(dop, wT_bf16(attn.proj.weight))
         dqkv = ops.attn_bwd(qkv, attn.qkv.bias, tbl, tblT, o, dO, lse, 2 * B, Sh, Sw, heads, ws, Lh, Lw, hd ** -0.5)
         dln = ops.gemm(dqkv, wT_bf16(attn.qkv.weight))
@@ -126,21 +135,17 @@ class _AdapterMlpBranch(torch.autograd.Function):
         act, pre = ops.gemm(ln, w_bf16(mlp.lin1.weight), bias=mlp.lin1.bias, act=1, want_pre=True)
         hm = ops.gemm(act, w_bf16(mlp.lin2.weight), bias=mlp.lin2.bias, residual=h2, out_dtype=torch.float32)
         ada = torch.empty((M, D), dtype=torch.float32, device=h.device)
-        acts, pres = [], []
-        for sl, (w1, b1, w2, b2) in ((slice(0, half), (w1x, b1x, w2x, b2x)), (slice(half, M), (w1y, b1y, w2y, b2y))):
-            a, p = _dense_fwd(ln[sl], w1, b1, act=True)
-            _dense_fwd(a, w2, b2, out=ada[sl])
-            acts.append(a)
-            pres.append(p)
+        a, p = _dense_fwd(ln, w1x, b1x, w1y, b1y, half, act=True)
+        _dense_fwd(a, w2x, b2x, w2y, b2y, half, out=ada)
         out = ops.adapter_mix(hm, ada, wx, wy)
-        ctx.save_for_backward(h2, mean, rstd, ln, pre, ada, acts[0], acts[1], pres[0], pres[1], w1x, w2x, w1y, w2y, wx, wy)
+        ctx.save_for_backward(h2, mean, rstd, ln, pre, ada, a, p, w1x, w2x, w1y, w2y, wx, wy)
         ctx.blk = blk
         ctx.params = (w1x, b1x, w2x, b2x, w1y, b1y, w2y, b2y, wx, wy)
         return out.view(h.shape)
 
     @staticmethod
     def backward(ctx, dout):
-        (h2, mean, rstd, ln, pre, ada, ax, ay, px, py, w1x, w2x, w1y, w2y, wx, wy) = ctx.saved_tensors
+        (h2, mean, rstd, ln, pre, ada, a, p, w1x, w2x, w1y, w2y, wx, wy) = ctx.saved_tensors
         blk = ctx.blk
         mlp = blk.mlp
         M, D = h2.shape
@@ -151,12 +156,10 @@ class _AdapterMlpBranch(torch.autograd.Function):
         # frozen MLP: dgrad only
         dpre = ops.gemm(d_bf, wT_bf16(mlp.lin2.weight), act=2, aux=pre)
         dln = ops.gemm(dpre, wT_bf16(mlp.lin1.weight))
-        grads = []
-        for sl, a, p, w1, w2 in ((slice(0, half), ax, px, w1x, w2x), (slice(half, M), ay, py, w1y, w2y)):
-            dp, dW2, db2 = _dense_bwd(dada[sl], a, w2, gelu_aux=p)
-            dxl, dW1, db1 = _dense_bwd(dp, ln[sl], w1)
-            ops.add_bf16(dxl, dln[sl], dln[sl])
-            grads += [dW1, db1, dW2, db2]
+        dp, dW2, db2 = _dense_bwd(dada, a, w2x, w2y, half, gelu_aux=p)
+        dxl, dW1, db1 = _dense_bwd(dp, ln, w1x, w1y, half)
+        ops.add_bf16(dxl, dln, dln)
+        grads = [dW1[0], db1[0], dW2[0], db2[0], dW1[1], db1[1], dW2[1], db2[1]]
         dh, _ = ops.layernorm_bwd(dln, h2, mean, rstd, blk.norm2.weight, dres=d2)
         return (dh.view(dout.shape), None) + deliver(ctx.params, grads + [dw[0:1], dw[1:2]])
 

@@ -37,6 +37,8 @@ def test_argument_errors_do_not_launch():
     assert rc == -1 and b"multiple of 8" in L.mfnet_last_error()
     with pytest.raises(_lib.MfnetError):
         _lib.call("mfnet_attn_fwd", 1, 1, 1, 1, 1, 1, 16, 16, 12, 32, 14, 27, 27, 64, 0.125, None)   # head dim 32: only 64 and 80 exist
+    rc = L.mfnet_gemm_bf16_grouped(16, 64, 16, 64, 4, 128, 64, 64, None, 0, 64, 2, 0, None, 0, None, 0, None, 0, 16, 0, 64, None)
+    assert rc == -1 and b"group strides" in L.mfnet_last_error()
     # weight-gradient GEMM: N / K must be multiples of 8; split count helper is pure host code
     rc = L.mfnet_gemm_tn_bf16(16, 64, 16, 64, 128, 60, 64, 16, 64, 1, None)
     assert rc == -1 and b"multiples of 8" in L.mfnet_last_error()

@@ -189,6 +189,27 @@ def test_im2col_patch_and_3x3(ops):
     assert rel_err(dx.view(G, S, S, C), refdx.permute(0, 2, 3, 1)) < 1e-6
 
 
+@pytest.mark.parametrize("M,N,K,rpg", [(8192, 192, 768, 4096), (8192, 768, 192, 4096), (800, 192, 768, 400), (512, 64, 64, 128)])
+def test_gemm_grouped_weights(ops, M, N, K, rpg):
+    """per-modality dense layers in one launch: rows of group g multiply w[g] and add bias[g] (whole-tile groups, and
+    groups that do not end on a 128-row tile -> launched one by one); GELU + pre-activation and the x gelu'(aux) dgrad."""
+    G = 2
+    a = rnd(M, K, seed=1).to(torch.bfloat16)
+    w = rnd(G, N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+    b = rnd(G, N, seed=3)
+    grp = (torch.arange(M, device="cuda") // rpg) % G
+    ref = torch.einsum("mk,mnk->mn", a.double(), w.double()[grp]) + b.double()[grp]
+    out = ops.gemm_grouped(a, w, bias=b, rows_per_group=rpg, out_dtype=torch.float32)
+    assert rel_err(out, ref) < 1e-5
+    act, pre = ops.gemm_grouped(a, w, bias=b, rows_per_group=rpg, act=1, want_pre=True)
+    assert rel_err(pre.float(), ref) < 5e-3 and rel_err(act.float(), F.gelu(ref)) < 5e-3
+    aux = rnd(M, N, seed=4).to(torch.bfloat16)
+    x = aux.double().requires_grad_()
+    F.gelu(x).sum().backward()
+    d = ops.gemm_grouped(a, w, rows_per_group=rpg, act=2, aux=aux, out_dtype=torch.float32)
+    assert rel_err(d, (ref - b.double()[grp]) * x.grad) < 1e-4
+
+
 # ------------------------------------------------------------------------------------------ attention
 def _attn_reference(qkv, bias, rel_h, rel_w, G, S, heads, ws):
     """fp64 restatement through the oracle's window/rel-pos functions: padded tokens carry qkv = bias."""
