@@ -150,6 +150,11 @@ int mfnet_transpose_bf16(const void* x, int64_t ld, void* y, int64_t M, int64_t 
  * out + s*N*ldo, to be summed by mfnet_reduce_splits (splits == 1: out is the result). */
 int mfnet_gemm_tn_bf16(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t M, int64_t N, int64_t K,
                        float* out, int64_t ldo, int splits, hipStream_t stream);
+/* n_groups independent products in one launch: group g multiplies rows [g*M, (g+1)*M) of dy and x (M = rows per group);
+ * partial tile (split s, group g) goes to out + (s*n_groups + g)*N*ldo. The per-modality adapter weight gradients
+ * (adapter.py:13-14 D_fc1 / D_fc2 of Img_ / DSM_ and MLPx_ / MLPy_Adapter). */
+int mfnet_gemm_tn_bf16_grouped(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t M, int64_t N, int64_t K,
+                               float* out, int64_t ldo, int splits, int n_groups, hipStream_t stream);
 int64_t mfnet_gemm_tn_splits(int64_t M, int64_t N, int64_t K);
 int mfnet_reduce_splits(const float* partial, float* out, int64_t n, int splits, float scale, int accumulate, hipStream_t stream);
 

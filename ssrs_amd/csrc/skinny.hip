@@ -335,14 +335,20 @@ extern "C" int mfnet_skinny_tn(const void* Y, int64_t ldy, const float* U, int64
 // The row range is cut into `splits`; split s stores its partial tile into out + s*N*ldo (mfnet_reduce_splits
 // sums them), exactly like the split-K mode of mfnet_gemm_bf16.
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ DY, int64_t ldy, const bf16_t* __restrict__ X, int64_t ldx,
-                                                      int64_t M, int N, int K, int64_t rows_per_split, float* __restrict__ out, int64_t ldo) {
+                                                      int64_t M, int N, int K, int64_t rows_per_split, float* __restrict__ out, int64_t ldo,
+                                                      int splits) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[4][2][32 * 128];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int n0 = blockIdx.y * 64;
   const int k0 = (blockIdx.x * 4 + wave) * 64;
   if (k0 >= K) return;
-  const int64_t r_begin = (int64_t)blockIdx.z * rows_per_split;
+  // blockIdx.z = split * n_groups + group: group g owns rows [g*M, (g+1)*M) of both operands; partial tile (split, group)
+  const int n_groups = gridDim.z / splits;
+  const int sp = blockIdx.z / n_groups, gz = blockIdx.z - sp * n_groups;
+  DY += (int64_t)gz * M * ldy;
+  X += (int64_t)gz * M * ldx;
+  const int64_t r_begin = (int64_t)sp * rows_per_split;
   int64_t r_end = r_begin + rows_per_split;
   if (r_end > M) r_end = M;
   out += (int64_t)blockIdx.z * N * ldo;
@@ -419,17 +425,30 @@ extern "C" int64_t mfnet_gemm_tn_splits(int64_t M, int64_t N, int64_t K) {
   return s < 1 ? 1 : s;
 }
 
-extern "C" int mfnet_gemm_tn_bf16(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t M, int64_t N, int64_t K,
-                                  float* out, int64_t ldo, int splits, hipStream_t stream) {
+static int gemm_tn_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t M, int64_t N, int64_t K,
+                          float* out, int64_t ldo, int splits, int n_groups, hipStream_t stream) {
   MF_CHECK_ARG(dy && x && out, "gemm_tn: null pointer");
+  MF_CHECK_ARG(n_groups >= 1 && (int64_t)n_groups * splits <= 65535, "gemm_tn: bad group count");
   MF_CHECK_ARG(M > 0 && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0, "gemm_tn: N=%lld and K=%lld must be multiples of 8", (long long)N, (long long)K);
   MF_CHECK_ARG(ldy % 8 == 0 && ldx % 8 == 0 && ldy >= N && ldx >= K && ldo >= K, "gemm_tn: bad leading dimensions");
   MF_CHECK_ARG(((uintptr_t)dy | (uintptr_t)x) % 16 == 0, "gemm_tn: operands must be 16-byte aligned");
   MF_CHECK_ARG(splits >= 1 && splits <= 65535 && N < (1ll << 31) && K < (1ll << 31), "gemm_tn: bad splits / shape");
   int64_t rps = ceil_div64(ceil_div64(M, splits), 32) * 32;
-  dim3 grid((unsigned)ceil_div64(K, 256), (unsigned)ceil_div64(N, 64), (unsigned)splits);
+  dim3 grid((unsigned)ceil_div64(K, 256), (unsigned)ceil_div64(N, 64), (unsigned)(splits * n_groups));
   MF_CHECK_ARG(grid.y <= 65535, "gemm_tn: N too large");
-  hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, stream, (const bf16_t*)dy, ldy, (const bf16_t*)x, ldx, M, (int)N, (int)K, rps, out, ldo);
+  hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, stream, (const bf16_t*)dy, ldy, (const bf16_t*)x, ldx, M, (int)N, (int)K, rps, out, ldo, splits);
   MF_LAUNCH_CHECK("gemm_tn");
   return MFNET_OK;
+}
+
+extern "C" int mfnet_gemm_tn_bf16(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t M, int64_t N, int64_t K,
+                                  float* out, int64_t ldo, int splits, hipStream_t stream) {
+  return gemm_tn_launch(dy, ldy, x, ldx, M, N, K, out, ldo, splits, 1, stream);
+}
+
+// n_groups independent products in one launch: group g takes rows [g*M, (g+1)*M) of dy and x (M = rows PER GROUP) and
+// writes its partial tiles to out + (s*n_groups + g)*N*ldo, s < splits - the two modalities' adapter weight gradients.
+extern "C" int mfnet_gemm_tn_bf16_grouped(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t M, int64_t N, int64_t K,
+                                          float* out, int64_t ldo, int splits, int n_groups, hipStream_t stream) {
+  return gemm_tn_launch(dy, ldy, x, ldx, M, N, K, out, ldo, splits, n_groups, stream);
 }

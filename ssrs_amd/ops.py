@@ -462,6 +462,21 @@ def transpose_pad(x, mult=64):
     return y
 
 
+def gemm_tn_grouped(dy, x, n_groups):
+    """n_groups independent dW_g[n,k] = sum over the rows of group g (M / n_groups consecutive rows each) of dy[m,n] x[m,k]
+    in one launch -> SplitSum of shape [G, N, K] (index it per group and hand the pieces to deliver)."""
+    _chk(dy, x)
+    assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.stride(-1) == 1 and x.stride(-1) == 1
+    d2, M, N, ldy = _rows2d(dy)
+    x2, M2, K, ldx = _rows2d(x)
+    assert M == M2 and M % n_groups == 0
+    Mg = M // n_groups
+    splits = int(_lib.lib().mfnet_gemm_tn_splits(Mg, N, K * n_groups))
+    part = torch.empty((splits, n_groups, N, K), dtype=torch.float32, device=dy.device)
+    call("mfnet_gemm_tn_bf16_grouped", d2.data_ptr(), ldy, x2.data_ptr(), ldx, Mg, N, K, part.data_ptr(), K, splits, n_groups, _stream(dy))
+    return SplitSum(part)
+
+
 def gemm_tn(dy, x, lazy=False):
     """dW[n,k] = sum_m dy[m,n] x[m,k]  (fp32 [N,K]); both bf16 row-major with M leading (views with a row
     stride are fine). The reduction runs over the rows (pixels / tokens): it is cut into splits whose partial

@@ -396,6 +396,14 @@ def test_split_sums_are_folded_into_the_gather(ops):
     l2 = ops.gemm_tn(dy, x, lazy=True)
     assert isinstance(l2, ops.SplitSum) and rel_err(l2.materialize(), e2) < 1e-6
     assert rel_err(l2.view(64, 3, 3, 64).permute(0, 3, 1, 2).materialize(), e2.view(64, 3, 3, 64).permute(0, 3, 1, 2)) < 1e-6
+    # two groups of rows in one launch (the per-modality adapter weight gradients)
+    dyg = rnd(8192, 192, seed=8).to(torch.bfloat16)
+    xg = rnd(8192, 768, seed=9).to(torch.bfloat16)
+    lg = ops.gemm_tn_grouped(dyg, xg, 2)
+    assert tuple(lg.shape) == (2, 192, 768)
+    for gi in range(2):
+        ref = dyg[gi * 4096:(gi + 1) * 4096].double().t() @ xg[gi * 4096:(gi + 1) * 4096].double()
+        assert rel_err(lg[gi].materialize(), ref) < 1e-5
 
 
 @pytest.mark.parametrize("M,N", [(4096, 768), (4096, 192), (16384, 256), (65536, 64), (1000, 3072), (77, 1280)])
