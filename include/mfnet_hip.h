@@ -171,7 +171,8 @@ int mfnet_gather_segments(const int64_t* desc, int n, int dst_dtype, int accumul
 
 /* ---- MMAdapter glue (adapter_fusionblock.py:104-108): out = h + w*ada_own + (1-w)*ada_other per modality
  * (rows [0,M/2) RGB, [M/2,M) DSM); backward gives d ada (bf16) and ADDS (d wx_Adapter, d wy_Adapter) into
- * dw[2]. gelu_fwd/bwd: exact GELU; add_bf16: elementwise sum; bias_grad: out[n] += sum_m dy[m,n]. */
+ * dw[16][2]: sixteen slots the caller sums (mfnet_gather_segments with red_n = 16), so no address takes more than a few
+ * dozen float atomics. gelu_fwd/bwd: exact GELU; add_bf16: elementwise sum; bias_grad: out[n] += sum_m dy[m,n]. */
 int mfnet_adapter_mix(const float* h, const float* ada, const float* wx, const float* wy, float* out, void* reserved,
                       int64_t M, int64_t D, hipStream_t stream);
 int mfnet_adapter_mix_bwd(const float* dh, const float* ada, const float* wx, const float* wy, void* dada, float* dw,

@@ -240,7 +240,9 @@ extern "C" int mfnet_adapter_mix(const float* h, const float* ada, const float* 
   return MFNET_OK;
 }
 // dada[x_t] = wx*dh[x_t] + (1-wy)*dh[y_t] ; dada[y_t] = (1-wx)*dh[x_t] + wy*dh[y_t]   (bf16 out)
-// dw[0] += sum dh[x]*(ada[x]-ada[y]) ; dw[1] += sum dh[y]*(ada[y]-ada[x])
+// dw[slot][0] += sum dh[x]*(ada[x]-ada[y]) ; dw[slot][1] += sum dh[y]*(ada[y]-ada[x]) over ADMIX_SLOTS slots (same-address
+// float atomics serialise: 2048 per address took 50 of the kernel's 61 us); the caller sums the slots
+#define ADMIX_SLOTS 16
 __global__ __launch_bounds__(256) void adapter_mix_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ ada,
                                                               const float* __restrict__ wx, const float* __restrict__ wy,
                                                               bf16_t* __restrict__ dada, float* __restrict__ dw, int64_t half4) {
@@ -260,8 +262,12 @@ __global__ __launch_bounds__(256) void adapter_mix_bwd_kernel(const float* __res
     sx += gx.x * dxs + gx.y * dys + gx.z * dzs + gx.w * dws;
     sy -= gy.x * dxs + gy.y * dys + gy.z * dzs + gy.w * dws;
   }
+  __shared__ float red[2][4];
   sx = wave_sum(sx); sy = wave_sum(sy);
-  if ((threadIdx.x & 63) == 0) { atomicAdd(dw, sx); atomicAdd(dw + 1, sy); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sx; red[1][threadIdx.x >> 6] = sy; }
+  __syncthreads();
+  if (threadIdx.x < 2)
+    atomicAdd(dw + 2 * (blockIdx.x % ADMIX_SLOTS) + threadIdx.x, (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]));
 }
 extern "C" int mfnet_adapter_mix_bwd(const float* dh, const float* ada, const float* wx, const float* wy, void* dada,
                                      float* dw, void* reserved, int64_t M, int64_t D, hipStream_t stream) {

@@ -427,10 +427,10 @@ def adapter_mix(h, ada, wx, wy, out=None):
 def adapter_mix_bwd(dh, ada, wx, wy):
     M, D = dh.shape
     dada = torch.empty((M, D), dtype=torch.bfloat16, device=dh.device)
-    dw = zeros(2, dh.device)
+    dw = zeros((16, 2), dh.device)                       # 16 slots of (d wx, d wy); summed by the gradient delivery
     call("mfnet_adapter_mix_bwd", dh.data_ptr(), ada.data_ptr(), wx.data_ptr(), wy.data_ptr(), dada.data_ptr(),
          dw.data_ptr(), None, M, D, _stream(dh))
-    return dada, dw
+    return dada, SplitSum(dw)
 
 
 def bias_grad(dy, out=None):
