@@ -127,8 +127,9 @@ int mfnet_attn_bwd(const void* qkv, const float* qkv_bias, const void* tbl, cons
                    const void* dout, const float* lse, void* dqkv, int64_t G, int64_t Sh, int64_t Sw,
                    int64_t heads, int64_t hd, int64_t ws, int64_t Lh, int64_t Lw, int64_t NT, float scale,
                    float* workspace, int64_t workspace_floats, hipStream_t stream);
-/* optional scratch of mfnet_attn_bwd (0 for most geometries; NULL is always accepted): for global attention over
- * 64-wide key rows the dQ kernel leaves each query's bias rows there and the dK/dV kernel does not recompute them. */
+/* scratch of mfnet_attn_bwd (required, 16-byte aligned): the dQ kernel leaves each query's rel-pos bias rows there and
+ * the dK/dV kernel, which visits every query of the window once per 64-key tile, reads them instead of repeating the
+ * table product. */
 int64_t mfnet_attn_bwd_workspace_floats(int64_t G, int64_t Sh, int64_t Sw, int64_t heads, int64_t ws);
 
 /* ---- data movement of the encoder. cast: fp32 <-> bf16, n % 8 == 0. im2col_patch: rgb [B,3,H,W] fp32 and

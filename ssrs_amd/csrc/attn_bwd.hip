@@ -26,7 +26,8 @@ struct AttnBwdParams {
   const bf16_t* dout;     // [G*T, D]
   const float* lse;       // [G, heads, T]
   bf16_t* dqkv;           // [G*T, 3D]
-  float* bias_ws;         // ROWT: [G, heads, T, ATT_WS_LD] fp32 - per query Th[kh] / scale (KH) then Tw[kw] / scale (KW); dQ writes, dK/dV reads
+  float* bias_ws;         // dQ writes, dK/dV reads, per query: ROWT [ATT_WS_LD] fp32 - Th[kh] / scale (KH) then Tw[kw] / scale (KW);
+                          // else [nsg][hi | lo][32 slots] bf16 - the slot rows of T' / scale (attn.hip)
 };
 #define ATT_WS_LD 128
 
@@ -101,6 +102,15 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : 2)) void attn_bw
     }
   } else {
     att_slot_fragments<NSG>(g, Trow, qp.qh, qp.qw, fq, nsg, tqh, tql);
+    if (qp.valid) {                   // the dK/dV kernel reads the query's slot rows (hi, lo) instead of recomputing them per key tile
+      unsigned char* wr = (unsigned char*)p.bias_ws + (((int64_t)gi * g.heads + head) * T + qp.tok) * (int64_t)(nsg * 128);
+#pragma unroll
+      for (int c = 0; c < NSG; ++c)
+        if (c < nsg) {
+          *reinterpret_cast<bf16x8_t*>(wr + c * 128 + 16 * fq) = tqh[c];
+          *reinterpret_cast<bf16x8_t*>(wr + c * 128 + 64 + 16 * fq) = tql[c];
+        }
+    }
   }
   const float cs = g.scale * 1.4426950408889634f;
 
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : 2)) void attn_bw
 // rows x 16 key columns a wave reads at once), instead of the T'.G^T indicator product.
 #define ATT_TS 68
 template <int NSG, int HD, bool ROWT>
-__global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 4 ? 2 : 3)) void attn_bwd_dkv_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 4 : (NSG == 4 ? 2 : 3))) void attn_bwd_dkv_kernel(const AttnBwdParams p) {
   typedef AttHd<HD> H;
   constexpr int KS = H::KS, UT = H::UT, ROWB = H::ROWB, CHS = H::CHS, CHV = H::CHV, RPI = H::RPI, NIT = ATT_QT / H::RPI;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -292,7 +302,6 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 4 ? 2 : 3)) void attn_bw
   int wi, wj, k0;
   att_locate_tile(g, blockIdx.x, &wi, &wj, &k0);
   const int nq = num_queries(g, wi, wj);      // real keys of a window == its real queries
-  const int TLD = g.NT + 4;
   const int nsg = (g.KH + g.KW + 31) >> 5;
 
   unsigned char* Q_lds = smem;                                   // [64][hd] swizzled
@@ -302,7 +311,6 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 4 ? 2 : 3)) void attn_bw
   unsigned char* TqH_lds = (unsigned char*)(delta_lds + ATT_QT); // [nsg][64][32 slots] bf16, hi part of T'/scale
   const int tq_bytes = ROWT ? ATT_QT * ATT_TS * 4 : nsg * ATT_QT * ATT_GROW;
   unsigned char* TqL_lds = TqH_lds + tq_bytes;                   // lo part
-  float* T_lds = (float*)(TqL_lds + tq_bytes);                   // [64][NT+4]
   float* Thq = (float*)TqH_lds;                                  // ROWT: [64 queries][ATT_TS] h term / scale by key row
   float* Twq = (float*)TqL_lds;                                  // ROWT: [64 queries][ATT_TS] w term / scale by key column
 
@@ -353,7 +361,6 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 4 ? 2 : 3)) void attn_bw
     }
     const QueryPos qw_ = query_pos(g, wi, wj, qc + wave * 16 + fr);      // this wave's 16 queries: table product
     constexpr bool from_ws = ROWT;                                        // the dQ kernel left the bias rows in global memory
-    bf16x8_t qfx[KS];
     float4 wsv0 = F4Z, wsv1 = F4Z, wsv2 = F4Z, wsv3 = F4Z;
     float wsh = 0.f;
     if constexpr (from_ws) {
@@ -363,8 +370,17 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 4 ? 2 : 3)) void attn_bw
       const float4* w4 = reinterpret_cast<const float4*>(wr + g.KH + 16 * (tid & 3));
       wsv0 = w4[0]; wsv1 = w4[1]; wsv2 = w4[2]; wsv3 = w4[3];
       wsh = wr[kp.qh];
-    } else {
-      att_load_row_frags<HD>(p.qkv + (row_base + qw_.tok) * ld + head * HD, fq, qw_.valid, qfx);
+    }
+    bf16x8_t th[NSG], tl[NSG];
+    if constexpr (!from_ws) {
+      const unsigned char* wr = (const unsigned char*)p.bias_ws + (((int64_t)gi * g.heads + head) * T + qw_.tok) * (int64_t)(nsg * 128);
+#pragma unroll
+      for (int c = 0; c < NSG; ++c) {
+        const int cc = c < nsg ? c : 0;
+        th[c] = *reinterpret_cast<const bf16x8_t*>(wr + cc * 128 + 16 * fq);
+        tl[c] = *reinterpret_cast<const bf16x8_t*>(wr + cc * 128 + 64 + 16 * fq);
+        if (!qw_.valid) { th[c] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}; tl[c] = th[c]; }
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -390,11 +406,7 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 4 ? 2 : 3)) void attn_bw
       w4[0] = wsv0; w4[1] = wsv1; w4[2] = wsv2; w4[3] = wsv3;
       if ((tid & 3) == 0) Thq[ql * ATT_TS + kp.qh] = wsh;
     } else {
-      float* Trow = T_lds + (wave * 16 + fr) * TLD;
-      att_table_product<HD>(p.tbl, g.NT, qfx, Trow, fr, fq);
       const int ql = wave * 16 + fr;
-      bf16x8_t th[NSG], tl[NSG];
-      att_slot_fragments<NSG>(g, Trow, qw_.qh, qw_.qw, fq, nsg, th, tl);
 #pragma unroll
       for (int c = 0; c < NSG; ++c) {
         if (c < nsg) {
@@ -477,13 +489,14 @@ int attn_fill_geom(AttnGeom* g, int64_t G, int64_t Sh, int64_t Sw, int64_t heads
 int attn_query_tiles(const AttnGeom& g);
 bool attn_row_tiles(const AttnGeom& g);
 
-// floats of optional scratch for mfnet_attn_bwd: non-zero only for global attention over 64-wide key rows, where the dQ
-// kernel hands each query's bias rows (Th, Tw) to the dK/dV kernel through it
+// floats of scratch mfnet_attn_bwd needs: the dQ kernel hands each query's rel-pos bias rows to the dK/dV kernel through
+// it (every key tile used to repeat the table product for all the window's queries)
 extern "C" int64_t mfnet_attn_bwd_workspace_floats(int64_t G, int64_t Sh, int64_t Sw, int64_t heads, int64_t ws) {
   if (G <= 0 || Sh <= 0 || Sw <= 0 || heads <= 0) return 0;
   AttnGeom g{};
   g.ws = (int)ws; g.KW = ws > 0 ? (int)ws : (int)Sw; g.KH = ws > 0 ? (int)ws : (int)Sh;
-  return attn_row_tiles(g) ? G * heads * Sh * Sw * ATT_WS_LD : 0;
+  const int64_t nsg = (g.KH + g.KW + 31) / 32;
+  return G * heads * Sh * Sw * (attn_row_tiles(g) ? (int64_t)ATT_WS_LD : 32 * nsg);
 }
 
 extern "C" int mfnet_attn_bwd(const void* qkv, const float* qkv_bias, const void* tbl, const void* tblT,
@@ -514,16 +527,12 @@ extern "C" int mfnet_attn_bwd(const void* qkv, const float* qkv_bias, const void
   }
   const int nsg = (p.g.KH + p.g.KW + 31) / 32;
   const int rowb = hd <= 64 ? AttHd<64>::ROWB : AttHd<80>::ROWB;
-  const size_t TL = (size_t)ATT_QT * (p.g.NT + 4) * 4;
   const size_t lds_dq = (size_t)att_region_a(p.g.NT, rowb) + (size_t)nsg * ATT_KC * ATT_GROW;
-  const bool rowt = attn_row_tiles(p.g) && workspace != nullptr;      // without the scratch the general kernels run
-  p.bias_ws = nullptr;
-  if (rowt) {
-    MF_CHECK_ARG(workspace_floats >= G * heads * Sh * Sw * ATT_WS_LD, "attn_bwd: workspace too small (mfnet_attn_bwd_workspace_floats)");
-    p.bias_ws = workspace;
-  }
-  const size_t lds_dkv = 2 * (size_t)ATT_QT * rowb + 2 * ATT_QT * 4 + 2 * (rowt ? (size_t)ATT_QT * ATT_TS * 4 : (size_t)nsg * ATT_QT * ATT_GROW) +
-                         (p.bias_ws ? 0 : TL);
+  const bool rowt = attn_row_tiles(p.g);
+  MF_CHECK_ARG(workspace && workspace_floats >= mfnet_attn_bwd_workspace_floats(G, Sh, Sw, heads, ws) && (uintptr_t)workspace % 16 == 0,
+               "attn_bwd: needs a 16-byte aligned workspace of mfnet_attn_bwd_workspace_floats(G, Sh, Sw, heads, ws) floats");
+  p.bias_ws = workspace;
+  const size_t lds_dkv = 2 * (size_t)ATT_QT * rowb + 2 * ATT_QT * 4 + 2 * (rowt ? (size_t)ATT_QT * ATT_TS * 4 : (size_t)nsg * ATT_QT * ATT_GROW);
   MF_CHECK_ARG(lds_dq <= 160 * 1024 && lds_dkv <= 160 * 1024, "attn_bwd: LDS demand too large");
   // the two kernels write disjoint column ranges of dqkv (q | k,v); window mode leaves nothing unwritten
   dim3 grid_q((unsigned)attn_query_tiles(p.g), (unsigned)heads, (unsigned)G);
