@@ -30,6 +30,14 @@ __device__ __forceinline__ float4 ld4(const void* p, int dt, int64_t i4) {
   const u32x2_t w = reinterpret_cast<const u32x2_t*>(p)[i4];
   return make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
 }
+// compile-time dtype: inside loops that keep several loads in flight the runtime switch of ld4 is a branch plus a full
+// memory wait per load (the bf16 arm unpacks at once), which serialises them
+template <bool BF>
+__device__ __forceinline__ float4 ld4t(const void* p, int64_t i4) {
+  if (!BF) return reinterpret_cast<const float4*>(p)[i4];
+  const u32x2_t w = reinterpret_cast<const u32x2_t*>(p)[i4];
+  return make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
+}
 __device__ __forceinline__ void st4(void* p, int dt, int64_t i4, float4 v) {
   if (dt == MFNET_F32) { reinterpret_cast<float4*>(p)[i4] = v; return; }
   u32x2_t w;
@@ -140,6 +148,7 @@ __device__ __forceinline__ void colreduce_finish(const ColRedParams& p, const in
   }
 }
 
+template <bool ABF, bool BBF>
 __global__ __launch_bounds__(256) void colreduce_kernel(const ColRedParams p) {
   __shared__ float4 red0[256], red1[256];
   const int C4 = p.C >> 2;
@@ -165,8 +174,8 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const ColRedParams p) {
         int64_t r = rb + (int64_t)k * nrl;
         r = r < r1 ? r : r1 - 1;
         const int64_t row = g * p.P + r;
-        av[k] = ld4(p.a, p.a_dt, row * C4 + cg);
-        if (p.mode != 0) bv[k] = ld4(p.b, p.b_dt, row * C4 + cg);
+        av[k] = ld4t<ABF>(p.a, row * C4 + cg);
+        if (p.mode != 0) bv[k] = ld4t<BBF>(p.b, row * C4 + cg);
         if (p.mode == 3) { mur[k] = p.mean[row]; rsr[k] = p.rstd[row]; }       // LayerNorm: per-ROW statistics
       }
 #pragma unroll
@@ -271,7 +280,14 @@ static int launch_colreduce(ColRedParams& p, int64_t G, float* workspace, unsign
   const bool wide = p.a_dt == MFNET_BF16 && (p.mode == 0 || (p.mode == 1 && p.b_dt == MFNET_BF16)) && p.C % 8 == 0 && ((uintptr_t)p.a % 16 == 0) &&
                     (p.mode == 0 || (uintptr_t)p.b % 16 == 0);
   if (wide) hipLaunchKernelGGL(colreduce_wide_kernel, dim3((unsigned)splits, (unsigned)G), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)splits, (unsigned)G), dim3(256), 0, stream, p);
+  else {
+    const dim3 grid((unsigned)splits, (unsigned)G);
+    const bool abf = p.a_dt == MFNET_BF16, bbf = p.mode != 0 && p.b_dt == MFNET_BF16;
+    if (abf && bbf) hipLaunchKernelGGL((colreduce_kernel<true, true>), grid, dim3(256), 0, stream, p);
+    else if (abf) hipLaunchKernelGGL((colreduce_kernel<true, false>), grid, dim3(256), 0, stream, p);
+    else if (bbf) hipLaunchKernelGGL((colreduce_kernel<false, true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((colreduce_kernel<false, false>), grid, dim3(256), 0, stream, p);
+  }
   MF_LAUNCH_CHECK(who);
   return MFNET_OK;
 }
@@ -487,6 +503,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
   }
 }
 // dx[y,x] = sum over the ext positions e that map to (y,x) of  sum_taps dy[e - tap + pad] * w[tap]
+template <bool DY_BF16>
 __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const void* __restrict__ dy, int dy_dt, const float* __restrict__ w,
                                                               float* __restrict__ dx, const DwParams p) {
   extern __shared__ float wl[];
@@ -512,7 +529,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const void* __rest
           for (int kx = 0; kx < p.k; ++kx) {
             const int ox = px - kx + p.pad;
             if (ox < 0 || ox >= p.W) continue;
-            acc = f4fma(ld4(dy, dy_dt, ((b * p.H + oy) * p.W + ox) * C4 + cg), reinterpret_cast<const float4*>(wl)[(ky * p.k + kx) * C4 + cg], acc);
+            acc = f4fma(ld4t<DY_BF16>(dy, ((b * p.H + oy) * p.W + ox) * C4 + cg), reinterpret_cast<const float4*>(wl)[(ky * p.k + kx) * C4 + cg], acc);
           }
         }
       }
@@ -521,6 +538,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const void* __rest
   }
 }
 // dw[c, tap] += sum_pixels dy[pix, c] * x_ext[pix + tap - pad, c]; thread = (tap slot, channel group); block = chunk of pixels
+template <bool DY_BF16>      // the gradient's dtype is a template argument: a runtime switch around each load put a branch and a
+                             // full memory wait between the loads of one iteration
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const void* __restrict__ dy, int dy_dt, const float* __restrict__ x,
                                                                 float* __restrict__ dw, float* __restrict__ dbias, const DwParams p,
                                                                 int64_t pix_per_block) {
@@ -533,14 +552,35 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const void* __re
   for (int tap = slot; tap < kk; tap += nslot) {
     const int ky = tap / p.k, kx = tap - ky * p.k;
     float4 acc = F4ZERO, bacc = F4ZERO;
-    for (int64_t pix = p0; pix < p1; ++pix) {
-      const int xx = (int)(pix % p.W), yy = (int)((pix / p.W) % p.H);
-      const int64_t b = pix / ((int64_t)p.W * p.H);
-      const float4 d = ld4(dy, dy_dt, pix * C4 + cg);
-      if (tap == 0) bacc = f4add(bacc, d);
-      const int sy = ext_map(yy + ky - p.pad, p.H, p.ext), sx = ext_map(xx + kx - p.pad, p.W, p.ext);
-      if (sy < 0 || sx < 0) continue;
-      acc = f4fma(d, reinterpret_cast<const float4*>(x)[((b * p.H + sy) * p.W + sx) * C4 + cg], acc);
+    // four pixels per iteration, their eight loads issued together (unconditionally: a pixel past the chunk or a tap
+    // that falls into the zero padding reads element 0 and is masked): the loop was one dependent round trip per pixel
+    // pixel coordinates advance by increments: the three 64-bit divisions per pixel this loop started with were most of its time
+    int xx = (int)(p0 % p.W), yy = (int)((p0 / p.W) % p.H);
+    int64_t rowb = (p0 / p.W) - yy;                  // b * H
+    for (int64_t pix = p0; pix < p1; pix += 4) {
+      float4 d[4], xv[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool in = pix + u < p1;
+        const int sy = ext_map(yy + ky - p.pad, p.H, p.ext), sx = ext_map(xx + kx - p.pad, p.W, p.ext);
+        ok[u] = in && sy >= 0 && sx >= 0;
+        const int64_t di = (in ? pix + u : p0) * C4 + cg;
+        if (DY_BF16) {
+          const u32x2_t w2 = reinterpret_cast<const u32x2_t*>(dy)[di];
+          d[u] = make_float4(bf16_lo(w2.x), bf16_hi(w2.x), bf16_lo(w2.y), bf16_hi(w2.y));
+        } else {
+          d[u] = reinterpret_cast<const float4*>(dy)[di];
+        }
+        if (!in) d[u] = F4ZERO;
+        xv[u] = reinterpret_cast<const float4*>(x)[ok[u] ? ((rowb + sy) * p.W + sx) * C4 + cg : cg];
+        if (++xx == p.W) { xx = 0; if (++yy == p.H) { yy = 0; rowb += p.H; } }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (tap == 0) bacc = f4add(bacc, d[u]);
+        if (ok[u]) acc = f4fma(d[u], xv[u], acc);
+      }
     }
     float* o = dw + (int64_t)(4 * cg) * kk + tap;
     atomicAdd(o, acc.x); atomicAdd(o + kk, acc.y); atomicAdd(o + 2 * kk, acc.z); atomicAdd(o + 3 * kk, acc.w);
@@ -571,7 +611,8 @@ extern "C" int mfnet_dwconv_bwd_data(const void* dy, int dy_dtype, const float* 
   DwParams p;
   int rc = dw_check(&p, B, H, W, C, k, ext, "dwconv_bwd_data");
   if (rc) return rc;
-  hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(grid_for(B * H * W * C / 4)), dim3(256), (size_t)(k * k * C * 4), stream, dy, dy_dtype, w, dx, p);
+  if (dy_dtype == MFNET_BF16) hipLaunchKernelGGL(dwconv_bwd_data_kernel<true>, dim3(grid_for(B * H * W * C / 4)), dim3(256), (size_t)(k * k * C * 4), stream, dy, dy_dtype, w, dx, p);
+  else hipLaunchKernelGGL(dwconv_bwd_data_kernel<false>, dim3(grid_for(B * H * W * C / 4)), dim3(256), (size_t)(k * k * C * 4), stream, dy, dy_dtype, w, dx, p);
   MF_LAUNCH_CHECK("dwconv_bwd_data");
   return MFNET_OK;
 }
@@ -585,7 +626,8 @@ extern "C" int mfnet_dwconv_bwd_weight(const void* dy, int dy_dtype, const float
   const int64_t npix = B * H * W;
   int64_t ppb = ceil_div64(npix, 512);
   if (ppb < 16) ppb = 16;
-  hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3((unsigned)ceil_div64(npix, ppb)), dim3(256), 0, stream, dy, dy_dtype, x, dw, dbias, p, ppb);
+  if (dy_dtype == MFNET_BF16) hipLaunchKernelGGL(dwconv_bwd_weight_kernel<true>, dim3((unsigned)ceil_div64(npix, ppb)), dim3(256), 0, stream, dy, dy_dtype, x, dw, dbias, p, ppb);
+  else hipLaunchKernelGGL(dwconv_bwd_weight_kernel<false>, dim3((unsigned)ceil_div64(npix, ppb)), dim3(256), 0, stream, dy, dy_dtype, x, dw, dbias, p, ppb);
   MF_LAUNCH_CHECK("dwconv_bwd_weight");
   return MFNET_OK;
 }
