@@ -264,13 +264,15 @@ int mfnet_act_bwd(const void* dy, int dy_dtype, const void* ref, int ref_dtype, 
 /* depthwise k x k conv, zero padding (k-1)/2, x / y [B,H,W,C] fp32, w [C, k*k] (nn.Conv2d(groups=C) weight):
  * FeatureRefinementHead.pa (k 3, bias, :329-331), SeparableConvBN (:64-73) of FRH.proj (k 3) and of
  * GlobalLocalAttention.proj (k 8). ext != 0 folds GLA's `F.pad(out, (0,1,0,1), 'reflect')` (:192-196) into the
- * indexing. bwd_weight ADDS into dw [C, k*k] and dbias [C] (optional). */
+ * indexing. bwd_weight ADDS into dw [slots][C, k*k] and dbias [slots][C] (optional): workgroup i adds into copy i % slots
+ * and the caller sums the copies (mfnet_gather_segments with red_n = slots; slots = 1: the plain gradient) - float atomics
+ * on one address cost ~140 ns each on this chip. */
 int mfnet_dwconv_fwd(const float* x, const float* w, const float* bias, float* y, int64_t B, int64_t H, int64_t W, int64_t C,
                      int64_t k, int ext, hipStream_t stream);
 int mfnet_dwconv_bwd_data(const void* dy, int dy_dtype, const float* w, float* dx, int64_t B, int64_t H, int64_t W, int64_t C,
                           int64_t k, int ext, hipStream_t stream);
 int mfnet_dwconv_bwd_weight(const void* dy, int dy_dtype, const float* x, float* dw, float* dbias, int64_t B, int64_t H,
-                            int64_t W, int64_t C, int64_t k, int ext, hipStream_t stream);
+                            int64_t W, int64_t C, int64_t k, int ext, int slots, hipStream_t stream);
 
 /* GlobalLocalAttention's window attention (:169-186): qkv [B*H*W, 3*heads*8] bf16 in the 1x1 qkv conv's
  * channel order (which, head, d); 8x8 windows (H, W multiples of 8), softmax(q.k*scale +

@@ -75,7 +75,7 @@ _SIGS = {
     "mfnet_act_bwd": [P, I, P, I, P, I, I, I64, P],
     "mfnet_dwconv_fwd": [P, P, P, P, I64, I64, I64, I64, I64, I, P],
     "mfnet_dwconv_bwd_data": [P, I, P, P, I64, I64, I64, I64, I64, I, P],
-    "mfnet_dwconv_bwd_weight": [P, I, P, P, P, I64, I64, I64, I64, I64, I, P],
+    "mfnet_dwconv_bwd_weight": [P, I, P, P, P, I64, I64, I64, I64, I64, I, I, P],
     "mfnet_gla_attn_fwd": [P, P, P, I64, I64, I64, I64, I64, I64, F, P],
     "mfnet_gla_attn_bwd": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, F, P],
     "mfnet_gla_pool_fwd": [P, P, P, P, I64, I64, I64, I64, P],

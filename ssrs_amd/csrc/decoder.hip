@@ -15,6 +15,7 @@
 //   up_final_* : bilinear x4 of the class maps into NCHW logits, and its adjoint
 //   maxpool2_*, se_*, frh_gate_* : fpn4, SqueezeAndExcitation / SEFusion, FRH pixel+channel attention
 #include "common.h"
+#include <stdlib.h>
 #include <float.h>
 
 static inline unsigned grid_for(int64_t work_items, int64_t cap = 16384) {
@@ -542,7 +543,7 @@ template <bool DY_BF16>      // the gradient's dtype is a template argument: a r
                              // full memory wait between the loads of one iteration
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const void* __restrict__ dy, int dy_dt, const float* __restrict__ x,
                                                                 float* __restrict__ dw, float* __restrict__ dbias, const DwParams p,
-                                                                int64_t pix_per_block) {
+                                                                int64_t pix_per_block, int slots) {
   const int C4 = p.C >> 2, kk = p.k * p.k;
   const int cg = threadIdx.x % C4, slot = threadIdx.x / C4, nslot = 256 / C4;
   const int64_t npix = (int64_t)p.B * p.H * p.W;
@@ -582,10 +583,14 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const void* __re
         if (ok[u]) acc = f4fma(d[u], xv[u], acc);
       }
     }
-    float* o = dw + (int64_t)(4 * cg) * kk + tap;
+    // same-address float atomics cost ~140 ns each on this chip: the workgroups spread over `slots` copies of dw / dbias
+    // that the caller sums (512 workgroups on one copy: 70 of the kernel's 110 us)
+    const int sl = blockIdx.x % slots;
+    float* o = dw + ((int64_t)sl * p.C + 4 * cg) * kk + tap;
     atomicAdd(o, acc.x); atomicAdd(o + kk, acc.y); atomicAdd(o + 2 * kk, acc.z); atomicAdd(o + 3 * kk, acc.w);
     if (dbias && tap == 0) {
-      atomicAdd(dbias + 4 * cg, bacc.x); atomicAdd(dbias + 4 * cg + 1, bacc.y); atomicAdd(dbias + 4 * cg + 2, bacc.z); atomicAdd(dbias + 4 * cg + 3, bacc.w);
+      float* ob = dbias + (int64_t)sl * p.C;
+      atomicAdd(ob + 4 * cg, bacc.x); atomicAdd(ob + 4 * cg + 1, bacc.y); atomicAdd(ob + 4 * cg + 2, bacc.z); atomicAdd(ob + 4 * cg + 3, bacc.w);
     }
   }
 }
@@ -616,18 +621,18 @@ extern "C" int mfnet_dwconv_bwd_data(const void* dy, int dy_dtype, const float* 
   MF_LAUNCH_CHECK("dwconv_bwd_data");
   return MFNET_OK;
 }
-// dw [C, k*k] and dbias [C] (optional) are ADDED into.
+// dw [slots][C, k*k] and dbias [slots][C] (optional) are ADDED into; the gradient is the sum over the slots.
 extern "C" int mfnet_dwconv_bwd_weight(const void* dy, int dy_dtype, const float* x, float* dw, float* dbias, int64_t B, int64_t H, int64_t W,
-                                       int64_t C, int64_t k, int ext, hipStream_t stream) {
-  MF_CHECK_ARG(dy && x && dw, "dwconv_bwd_weight: null pointer");
+                                       int64_t C, int64_t k, int ext, int slots, hipStream_t stream) {
+  MF_CHECK_ARG(dy && x && dw && slots >= 1 && slots <= 64, "dwconv_bwd_weight: null pointer / slots not in [1, 64]");
   DwParams p;
   int rc = dw_check(&p, B, H, W, C, k, ext, "dwconv_bwd_weight");
   if (rc) return rc;
   const int64_t npix = B * H * W;
-  int64_t ppb = ceil_div64(npix, 512);
+  int64_t ppb = ceil_div64(npix, 1024);
   if (ppb < 16) ppb = 16;
-  if (dy_dtype == MFNET_BF16) hipLaunchKernelGGL(dwconv_bwd_weight_kernel<true>, dim3((unsigned)ceil_div64(npix, ppb)), dim3(256), 0, stream, dy, dy_dtype, x, dw, dbias, p, ppb);
-  else hipLaunchKernelGGL(dwconv_bwd_weight_kernel<false>, dim3((unsigned)ceil_div64(npix, ppb)), dim3(256), 0, stream, dy, dy_dtype, x, dw, dbias, p, ppb);
+  if (dy_dtype == MFNET_BF16) hipLaunchKernelGGL(dwconv_bwd_weight_kernel<true>, dim3((unsigned)ceil_div64(npix, ppb)), dim3(256), 0, stream, dy, dy_dtype, x, dw, dbias, p, ppb, slots);
+  else hipLaunchKernelGGL(dwconv_bwd_weight_kernel<false>, dim3((unsigned)ceil_div64(npix, ppb)), dim3(256), 0, stream, dy, dy_dtype, x, dw, dbias, p, ppb, slots);
   MF_LAUNCH_CHECK("dwconv_bwd_weight");
   return MFNET_OK;
 }

@@ -607,16 +607,18 @@ def dwconv_fwd(x, w, bias, B, H, W, k, ext):
 
 
 def dwconv_bwd(dy, x, w, B, H, W, k, ext, want_bias=False):
-    """-> (dx fp32, dw like w, dbias | None)."""
+    """-> (dx fp32, dw like w, dbias | None); dw / dbias are SplitSums (materialize() for a tensor)."""
     _chk(dy, x, w)
     C = x.shape[-1]
     assert dy.is_contiguous() and x.is_contiguous() and x.dtype == torch.float32
     dx = torch.empty_like(x)
     call("mfnet_dwconv_bwd_data", dy.data_ptr(), _dt(dy), w.data_ptr(), dx.data_ptr(), B, H, W, C, k, 1 if ext else 0, _stream(x))
-    dw = zeros(w.shape, x.device)
-    db = zeros(C, x.device) if want_bias else None
-    call("mfnet_dwconv_bwd_weight", dy.data_ptr(), _dt(dy), x.data_ptr(), dw.data_ptr(), _p(db), B, H, W, C, k, 1 if ext else 0, _stream(x))
-    return dx, dw, db
+    slots = 32                                           # copies of dw / db the workgroups spread their atomics over
+    dw = zeros((slots,) + tuple(w.shape), x.device)
+    db = zeros((slots, C), x.device) if want_bias else None
+    call("mfnet_dwconv_bwd_weight", dy.data_ptr(), _dt(dy), x.data_ptr(), dw.data_ptr(), _p(db), B, H, W, C, k, 1 if ext else 0, slots,
+         _stream(x))
+    return dx, SplitSum(dw), (SplitSum(db) if want_bias else None)       # summed over the slots by the gradient delivery
 
 
 def gla_attn_fwd(qkv, table, B, H, W, heads, scale):
