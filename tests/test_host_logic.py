@@ -168,3 +168,37 @@ def test_multistep_lr_schedule():
         ref_opt.step()
         sched.step()
         eng.scheduler_step()
+
+
+def test_percentile_stretch_matches_numpy_bit_for_bit():
+    """inference.py:474 `np.percentile(valid_pixels, (2, 98))`: the device path sorts once and interpolates the two
+    neighbours of each virtual index on the host the way numpy's 'linear' method does (b - a in the array's dtype,
+    the lerp in float64, the upper arm for t >= 0.5). Host logic only: runs on CPU tensors."""
+    from ssrs_amd import ops
+    rng = np.random.default_rng(7)
+    for n in (1, 2, 3, 7, 50, 51, 1000, 100003):
+        for scale in (1.0, 50.0, 1e-3):
+            x = (rng.normal(size=n) * scale).astype(np.float32)
+            got = ops.percentiles_2_98(torch.from_numpy(x))
+            ref = np.percentile(x, (2, 98))
+            assert got[0] == ref[0] and got[1] == ref[1], (n, scale, got, ref.tolist())
+
+
+def test_normalize_image_restatement_on_a_hand_case():
+    """The oracle's _normalize_image restatement (inference.py:444-496) on values checked by hand: uint8 /255 then
+    ImageNet statistics, nodata = any channel equal to the nodata value, nodata pixels zeroed in every channel; a
+    single-band DEM keeps its raw values."""
+    from oracle import mfnet_ref as R
+    rgb = np.zeros((3, 2, 2), dtype=np.uint8)
+    rgb[:, 0, 0] = (255, 128, 0)          # channel 2 hits nodata 0 -> the whole pixel is nodata
+    rgb[:, 0, 1] = (255, 255, 255)
+    rgb[:, 1, 0] = (51, 102, 204)
+    out, mask = R.normalize_image(rgb, True, 0)
+    assert mask.tolist() == [[True, False], [False, True]]                  # (1,1) is all zeros -> nodata too
+    mean, std = np.array([0.485, 0.456, 0.406], np.float32), np.array([0.229, 0.224, 0.225], np.float32)
+    assert np.array_equal(out[:, 0, 0], np.zeros(3, np.float32)) and np.array_equal(out[:, 1, 1], np.zeros(3, np.float32))
+    assert np.allclose(out[:, 0, 1], (1.0 - mean) / std, rtol=0, atol=1e-6)
+    assert np.allclose(out[:, 1, 0], (np.array([51, 102, 204], np.float32) / 255 - mean) / std, rtol=0, atol=1e-6)
+    dem = np.array([[1.5, -9999.0], [20.0, 3.0]], dtype=np.float32)
+    o2, m2 = R.normalize_image(dem, False, -9999)
+    assert m2.tolist() == [[False, True], [False, False]] and o2.tolist() == [[1.5, 0.0], [20.0, 3.0]] and o2.dtype == np.float32
