@@ -166,7 +166,11 @@ class TrainEngine:
     def _finish_exchange(self):
         if self.world == 1 and not (self.exchange_when_alone and dist.is_initialized()):
             return
-        if not self.overlap or any(c != s for c, s in zip(self._pending, self._bucket_size)):
+        if not self.overlap and not self._works:
+            # nothing to overlap with (graph replay / overlap off): ONE all-reduce over the whole flat gradient buffer -
+            # every collective costs a launch and a stream hand-off of its own
+            self._works.append(dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        elif any(c != s for c, s in zip(self._pending, self._bucket_size)):
             # a bucket whose hooks did not all fire (a tensor without gradient this step) is reduced whole
             done = len(self._works)
             for b in range(done, len(self.bucket_bounds)):
