@@ -19,6 +19,7 @@ What changes relative to the reference loop (the arithmetic of one step does not
 """
 from __future__ import annotations
 
+import os
 import math
 import time
 from dataclasses import dataclass, field
@@ -134,6 +135,8 @@ class TrainEngine:
         # launch per module instead of one autograd `grad += g` per tensor); the bucket counters are notified
         # from there. The autograd hook stays for any tensor whose gradient still arrives the ordinary way.
         self.bank = ParamBank()
+        # overlapped exchange: buckets need their gradients at once. MFNET_EAGER_DELIVERY=1 is the A/B switch of the measurement.
+        self.bank.defer = not (self.world > 1 and self.overlap) and os.environ.get("MFNET_EAGER_DELIVERY", "0") != "1"
         self.arena = ops.ZeroArena()
         for i, p in enumerate(self.params):
             notify = None
