@@ -64,6 +64,7 @@ class ParamBank:
         else:
             self._pending, self._notes = [], []
         ParamBank.active = None
+        ops._twin[0] = None
         return False
 
 

@@ -280,6 +280,26 @@ def cast(x, dtype):
     return y
 
 
+# The residual-stream gradient of a ViT block is written by the LayerNorm backward kernel in fp32 (for the residual add
+# of the next backward) and, by the same launch, in bf16 (the GEMM operand of the next backward). Autograd carries only
+# the fp32 tensor, so the bf16 copy waits here for the next backward to claim it: ONE slot, holding the fp32 tensor too
+# (its memory cannot be reused while the slot is set), claimed by address, shape and version counter.
+_twin = [None]
+
+
+def remember_bf16_twin(d, d_bf):
+    _twin[0] = (d, d_bf, d._version)
+
+
+def bf16_of(d2):
+    """bf16 copy of the fp32 gradient d2: the stored twin if d2 is that very tensor, else a cast launch."""
+    t, _twin[0] = _twin[0], None
+    if t is not None and t[0].data_ptr() == d2.data_ptr() and t[0].numel() == d2.numel() and t[0]._version == t[2] \
+            and d2.is_contiguous():
+        return t[1].view(d2.shape)
+    return cast(d2, torch.bfloat16)
+
+
 def im2col_patch(rgb, dsm, patch=16):
     """rgb [B,3,H,W] fp32, dsm [B,H,W] fp32 -> [2*B*(H/P)*(W/P), 3*P*P] bf16 (rgb rows first)."""
     _chk(rgb, dsm)

@@ -180,7 +180,7 @@ class _LoraAttnBranch(torch.autograd.Function):
         r = Ax.shape[0] // 2
         hd = D // heads
         d2 = dout.reshape(M, D).contiguous()
-        d_bf = ops.cast(d2, BF)
+        d_bf = ops.bf16_of(d2)
         dO = ops.gemm(d_bf, wT_bf16(attn.proj.weight))
         dqkv = ops.attn_bwd(qkv, attn.qkv.bias, tbl, tblT, o, dO, lse, 2 * B, Sh, Sw, heads, ws, Lh, Lw, hd ** -0.5)
         s = 1.0 / r
@@ -188,7 +188,8 @@ class _LoraAttnBranch(torch.autograd.Function):
         dVx, dVy = _tn_groups(dqkv, a, half, False, s)
         dAx, dAy = _tn_groups(ln, da, half, True)
         dln = ops.gemm(dqkv, wT_bf16(attn.qkv.weight), U=da, V=_stack2("A", Ax, Ay, transpose=True), rows_per_group=half, n_groups=2)
-        dh, _ = ops.layernorm_bwd(dln, h2, mean, rstd, blk.norm1.weight, dres=d2)
+        dh, dh_bf = ops.layernorm_bwd(dln, h2, mean, rstd, blk.norm1.weight, dres=d2, want_bf16=True)
+        ops.remember_bf16_twin(dh, dh_bf)
         rows_q, rows_v = slice(0, D), slice(D, 2 * D)
         grads = deliver((Ax, Ay, Bx, By), (dAx, dAy, [(rows_q, dVx[:D, :r]), (rows_v, dVx[2 * D:, r:])],
                                            [(rows_q, dVy[:D, :r]), (rows_v, dVy[2 * D:, r:])]))
@@ -248,10 +249,11 @@ class _LoraMlpBranch(torch.autograd.Function):
         M, D = h2.shape
         half = M // 2
         d2 = dout.reshape(M, D).contiguous()
-        d_bf = ops.cast(d2, BF)
+        d_bf = ops.bf16_of(d2)
         dpre, g2 = _mix_linear_bwd(d_bf, act, blk.mlp.lin2, (a2, U2), half, gelu_aux=pre)
         dln, g1 = _mix_linear_bwd(dpre, ln, blk.mlp.lin1, (a1, U1), half)
-        dh, _ = ops.layernorm_bwd(dln, h2, mean, rstd, blk.norm2.weight, dres=d2)
+        dh, dh_bf = ops.layernorm_bwd(dln, h2, mean, rstd, blk.norm2.weight, dres=d2, want_bf16=True)
+        ops.remember_bf16_twin(dh, dh_bf)
         return (dh.view(dout.shape), None) + deliver(blk._mlp_params(), g1 + g2)     # order of LoraBlock._mlp_params()
 
 

@@ -108,7 +108,7 @@ class _AdapterAttnBranch(torch.autograd.Function):
         half = M // 2
         hd = D // heads
         d2 = dout.reshape(M, D).contiguous()
-        d_bf = ops.cast(d2, BF)
+        d_bf = ops.bf16_of(d2)
         dop = torch.empty_like(d_bf)
         dpre, dW2, db2 = _dense_bwd(d_bf, a, w2x, w2y, half, gelu_aux=p)
         dxo, dW1, db1 = _dense_bwd(dpre, op, w1x, w1y, half)
@@ -117,7 +117,8 @@ class _AdapterAttnBranch(torch.autograd.Function):
         dO = ops.gemm(dop, wT_bf16(attn.proj.weight))
         dqkv = ops.attn_bwd(qkv, attn.qkv.bias, tbl, tblT, o, dO, lse, 2 * B, Sh, Sw, heads, ws, Lh, Lw, hd ** -0.5)
         dln = ops.gemm(dqkv, wT_bf16(attn.qkv.weight))
-        dh, _ = ops.layernorm_bwd(dln, h2, mean, rstd, blk.norm1.weight, dres=d2)
+        dh, dh_bf = ops.layernorm_bwd(dln, h2, mean, rstd, blk.norm1.weight, dres=d2, want_bf16=True)
+        ops.remember_bf16_twin(dh, dh_bf)
         return (dh.view(dout.shape), None, None) + deliver(ctx.params, grads)
 
 
@@ -151,7 +152,7 @@ class _AdapterMlpBranch(torch.autograd.Function):
         M, D = h2.shape
         half = M // 2
         d2 = dout.reshape(M, D).contiguous()
-        d_bf = ops.cast(d2, BF)
+        d_bf = ops.bf16_of(d2)
         dada, dw = ops.adapter_mix_bwd(d2, ada, wx, wy)
         # frozen MLP: dgrad only
         dpre = ops.gemm(d_bf, wT_bf16(mlp.lin2.weight), act=2, aux=pre)
@@ -160,7 +161,8 @@ class _AdapterMlpBranch(torch.autograd.Function):
         dxl, dW1, db1 = _dense_bwd(dp, ln, w1x, w1y, half)
         ops.add_bf16(dxl, dln, dln)
         grads = [dW1[0], db1[0], dW2[0], db2[0], dW1[1], db1[1], dW2[1], db2[1]]
-        dh, _ = ops.layernorm_bwd(dln, h2, mean, rstd, blk.norm2.weight, dres=d2)
+        dh, dh_bf = ops.layernorm_bwd(dln, h2, mean, rstd, blk.norm2.weight, dres=d2, want_bf16=True)
+        ops.remember_bf16_twin(dh, dh_bf)
         return (dh.view(dout.shape), None) + deliver(ctx.params, grads + [dw[0:1], dw[1:2]])
 
 
