@@ -433,3 +433,40 @@ def test_colsum_coldot_deterministic(ops, G, P, C, dt):
     for _ in range(5):
         s2, sq2 = ops.colsum(x, G, P, want_sq=True)
         assert torch.equal(s, s2) and torch.equal(sq, sq2) and torch.equal(d, ops.coldot(x, y, G, P))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,Cr,relu6,bias", [(1, 256, 16, False, True), (16, 256, 16, False, True), (5, 64, 4, True, False),
+                                               (20, 256, 16, False, True), (33, 64, 4, True, False)])
+def test_se_gate_forward_backward_vs_float64_autograd(B, C, Cr, relu6, bias):
+    """squeeze-excite gate (unetformer_mmsam.py:251-266, 333-337), SE (C=256, Cr=16, biases, ReLU) and FRH (C=64, Cr=4,
+    ReLU6) shapes over several batch sizes, against torch autograd in float64 (fp32 tolerance 1e-5 relative to the largest entry)."""
+    import torch
+    from ssrs_amd import ops
+    gen = torch.Generator().manual_seed(B * 1000 + C)
+    P = 64
+    pooled = (torch.randn(B, C, generator=gen) * P).cuda()
+    W1 = (torch.randn(Cr, C, generator=gen) * 0.2).cuda()
+    W2 = (torch.randn(C, Cr, generator=gen) * 0.2).cuda()
+    b1 = (torch.randn(Cr, generator=gen) * 0.1).cuda() if bias else None
+    b2 = (torch.randn(C, generator=gen) * 0.1).cuda() if bias else None
+    dg = torch.randn(B, C, generator=gen).cuda()
+    z, g = ops.se_gate_fwd(pooled, P, W1, b1, W2, b2, relu6)
+    dpool, dW1, db1, dW2, db2 = ops.se_gate_bwd(dg, pooled, P, W1, W2, relu6, z, g, bias)
+
+    leaves = [t.double().requires_grad_(True) if t is not None else None for t in (pooled, W1, b1, W2, b2)]
+    p64, w1, bb1, w2, bb2 = leaves
+    h = (p64 / P) @ w1.t() + (bb1 if bias else 0.0)
+    h = torch.clamp(h, 0.0, 6.0) if relu6 else torch.relu(h)
+    gate = torch.sigmoid(h @ w2.t() + (bb2 if bias else 0.0))
+    gate.backward(dg.double())
+
+    def close(a, b):
+        assert (a.double() - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item())
+    close(g, gate.detach())
+    close(dpool, p64.grad)           # d/d(pooled sum) = d/d(mean) / P
+    close(dW1, w1.grad)
+    close(dW2, w2.grad)
+    if bias:
+        close(db1, bb1.grad)
+        close(db2, bb2.grad)
