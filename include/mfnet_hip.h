@@ -243,6 +243,12 @@ int mfnet_layernorm_bwd_weights(const void* dy, int dy_dtype, const void* x, int
 int mfnet_bn_finalize(const float* sum, const float* sumsq, float* mean, float* rstd, float* run_mean, float* run_var,
                       int64_t* num_batches_tracked, int64_t C, int64_t n_rows, float eps, float momentum, int training,
                       hipStream_t stream);
+/* finalize (training) + apply in ONE launch: mean / rstd are derived from the column sums by every workgroup and stored
+ * (with the running-statistics update) by the first; same arithmetic as the two calls above. C <= 1024. */
+int mfnet_bn_train_apply(const void* x, int x_dtype, const float* sum, const float* sumsq, float* mean, float* rstd, float* run_mean,
+                         float* run_var, int64_t* num_batches_tracked, float eps, float momentum, const float* gamma,
+                         const float* beta, int act, const float* chan_scale, int64_t rows_per_image, void* y, int y_dtype, void* y2,
+                         int y2_dtype, int64_t rows, int64_t C, hipStream_t stream);
 int mfnet_bn_apply(const void* x, int x_dtype, const float* mean, const float* rstd, const float* gamma, const float* beta,
                    int act, const float* chan_scale, int64_t rows_per_image, void* y, int y_dtype, void* y2, int y2_dtype,
                    int64_t rows, int64_t C, hipStream_t stream);

@@ -68,6 +68,7 @@ _SIGS = {
     "mfnet_coldot": [P, I, P, I, P, I64, I64, I64, P, P, P],
     "mfnet_layernorm_bwd_weights": [P, I, P, I, P, P, P, P, I64, I64, P, P, P],
     "mfnet_bn_finalize": [P, P, P, P, P, P, P, I64, I64, F, F, I, P],
+    "mfnet_bn_train_apply": [P, I, P, P, P, P, P, P, P, F, F, P, P, I, P, I64, P, I, P, I, I64, I64, P],
     "mfnet_bn_apply": [P, I, P, P, P, P, I, P, I64, P, I, P, I, I64, I64, P],
     "mfnet_bn_bwd_reduce": [P, I, P, I, P, P, P, P, I, P, I64, P, P, I64, I64, P, P, P],
     "mfnet_bn_bwd_apply": [P, I, P, I, P, P, P, P, I, P, I64, P, P, I, P, I, I64, I64, P],

@@ -383,6 +383,61 @@ extern "C" int mfnet_bn_apply(const void* x, int x_dtype, const float* mean, con
   MF_LAUNCH_CHECK("bn_apply");
   return MFNET_OK;
 }
+// Training forward in one launch: every workgroup derives mean / rstd of all channels from the column sums (the arithmetic of
+// bn_finalize_kernel, kept in LDS), workgroup 0 also stores them for the backward pass and updates the running statistics.
+#define BN_MAXC 1024
+__global__ __launch_bounds__(256) void bn_train_apply_kernel(const void* __restrict__ x, int x_dt, const float* __restrict__ sum, const float* __restrict__ sumsq,
+                                                             float n, float eps, float momentum, float* __restrict__ mean, float* __restrict__ rstd,
+                                                             float* __restrict__ run_mean, float* __restrict__ run_var, int64_t* __restrict__ nbt,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                             const float* __restrict__ cs, int64_t rpi, void* __restrict__ y, int y_dt,
+                                                             void* __restrict__ y2, int y2_dt, int64_t rows, int C4) {
+  __shared__ __attribute__((aligned(16))) float mu_s[BN_MAXC], rs_s[BN_MAXC];
+  const int C = 4 * C4;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float m = sum[c] / n;
+    float v = sumsq[c] / n - m * m;
+    v = v > 0.f ? v : 0.f;
+    const float r = rsqrtf(v + eps);
+    mu_s[c] = m; rs_s[c] = r;
+    if (blockIdx.x == 0) {
+      mean[c] = m; rstd[c] = r;
+      if (run_mean) {
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * m;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (n > 1.f ? v * n / (n - 1.f) : v);
+      }
+      if (nbt && c == 0) nbt[0] += 1;
+    }
+  }
+  __syncthreads();
+  const int64_t total = rows * C4;
+  GS_LOOP(i, total) {
+    const int cg = (int)(i % C4);
+    const int64_t row = i / C4;
+    const float4 v = ld4(x, x_dt, i);
+    const float4 mu = reinterpret_cast<const float4*>(mu_s)[cg], rs = reinterpret_cast<const float4*>(rs_s)[cg];
+    const float4 ga = reinterpret_cast<const float4*>(gamma)[cg], be = reinterpret_cast<const float4*>(beta)[cg];
+    float4 o = make_float4(act_f(fmaf((v.x - mu.x) * rs.x, ga.x, be.x), act), act_f(fmaf((v.y - mu.y) * rs.y, ga.y, be.y), act),
+                           act_f(fmaf((v.z - mu.z) * rs.z, ga.z, be.z), act), act_f(fmaf((v.w - mu.w) * rs.w, ga.w, be.w), act));
+    if (cs) o = f4mul(o, reinterpret_cast<const float4*>(cs)[(row / rpi) * C4 + cg]);
+    st4(y, y_dt, i, o);
+    if (y2) st4(y2, y2_dt, i, o);
+  }
+}
+extern "C" int mfnet_bn_train_apply(const void* x, int x_dtype, const float* sum, const float* sumsq, float* mean, float* rstd, float* run_mean,
+                                    float* run_var, int64_t* num_batches_tracked, float eps, float momentum, const float* gamma,
+                                    const float* beta, int act, const float* chan_scale, int64_t rows_per_image, void* y, int y_dtype, void* y2,
+                                    int y2_dtype, int64_t rows, int64_t C, hipStream_t stream) {
+  MF_CHECK_ARG(x && sum && sumsq && mean && rstd && gamma && beta && y && C > 0 && C % 4 == 0 && C <= BN_MAXC && act >= 0 && act <= 2 && rows > 0,
+               "bn_train_apply: bad args (C a multiple of 4, at most %d; rows > 0)", BN_MAXC);
+  MF_CHECK_ARG((run_mean == nullptr) == (run_var == nullptr), "bn_train_apply: running mean and variance come together");
+  MF_CHECK_ARG(!chan_scale || rows_per_image > 0, "bn_train_apply: chan_scale needs rows_per_image");
+  hipLaunchKernelGGL(bn_train_apply_kernel, dim3(grid_for(rows * C / 4)), dim3(256), 0, stream, x, x_dtype, sum, sumsq, (float)rows, eps, momentum,
+                     mean, rstd, run_mean, run_var, num_batches_tracked, gamma, beta, act, chan_scale, rows_per_image, y, y_dtype, y2, y2_dtype,
+                     rows, (int)(C / 4));
+  MF_LAUNCH_CHECK("bn_train_apply");
+  return MFNET_OK;
+}
 // sums for the backward: dsum[c] += sum dy', dxh[c] += sum dy'*xhat  (= dbeta, dgamma)
 extern "C" int mfnet_bn_bwd_reduce(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd,
                                    const float* gamma, const float* beta, int act, const float* chan_scale, int64_t rows_per_image,

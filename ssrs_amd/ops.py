@@ -570,6 +570,14 @@ def bn_forward(x, gamma, beta, run_mean, run_var, nbt, training, eps=1e-5, momen
     rows, C = x.shape
     assert x.is_contiguous()
     st = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    y = torch.empty((rows, C), dtype=out_dtype, device=x.device)
+    y2 = torch.empty((rows, C), dtype=out2_dtype, device=x.device) if out2_dtype is not None else None
+    if training and C <= 1024:
+        s, sq = colsum(x, 1, rows, want_sq=True)
+        call("mfnet_bn_train_apply", x.data_ptr(), _dt(x), s.data_ptr(), sq.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), _p(run_mean),
+             _p(run_var), _p(nbt), float(eps), float(momentum), gamma.data_ptr(), beta.data_ptr(), act, _p(chan_scale), rows_per_image,
+             y.data_ptr(), _dt(y), _p(y2), _dt(y2) if y2 is not None else 0, rows, C, _stream(x))
+        return y, y2, st[0], st[1]
     if training:
         s, sq = colsum(x, 1, rows, want_sq=True)
         call("mfnet_bn_finalize", s.data_ptr(), sq.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), _p(run_mean), _p(run_var),
@@ -577,8 +585,6 @@ def bn_forward(x, gamma, beta, run_mean, run_var, nbt, training, eps=1e-5, momen
     else:
         call("mfnet_bn_finalize", None, None, st[0].data_ptr(), st[1].data_ptr(), run_mean.data_ptr(), run_var.data_ptr(), None,
              C, rows, float(eps), float(momentum), 0, _stream(x))
-    y = torch.empty((rows, C), dtype=out_dtype, device=x.device)
-    y2 = torch.empty((rows, C), dtype=out2_dtype, device=x.device) if out2_dtype is not None else None
     call("mfnet_bn_apply", x.data_ptr(), _dt(x), st[0].data_ptr(), st[1].data_ptr(), gamma.data_ptr(), beta.data_ptr(), act,
          _p(chan_scale), rows_per_image, y.data_ptr(), _dt(y), _p(y2), _dt(y2) if y2 is not None else 0, rows, C, _stream(x))
     return y, y2, st[0], st[1]

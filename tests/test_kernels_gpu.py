@@ -470,3 +470,38 @@ def test_se_gate_forward_backward_vs_float64_autograd(B, C, Cr, relu6, bias):
     if bias:
         close(db1, bb1.grad)
         close(db2, bb2.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,C,act", [(4096, 64, 1), (1000, 256, 0), (64, 1024, 2)])
+def test_bn_train_apply_equals_finalize_then_apply(rows, C, act):
+    """mfnet_bn_train_apply (one launch) against mfnet_bn_finalize + mfnet_bn_apply: outputs, saved statistics and the
+    running-statistics update (nn.BatchNorm2d, momentum 0.1, unbiased running variance) bit for bit."""
+    import torch
+    from ssrs_amd import ops
+    gen = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=gen) * 2 + 0.5).cuda()
+    gamma = torch.rand(C, generator=gen).cuda() + 0.5
+    beta = torch.randn(C, generator=gen).cuda()
+    rm0, rv0 = torch.randn(C, generator=gen).cuda(), torch.rand(C, generator=gen).cuda() + 0.5
+
+    rm_a, rv_a, nbt_a = rm0.clone(), rv0.clone(), torch.zeros(1, dtype=torch.int64, device="cuda")
+    y_a, y2_a, mean_a, rstd_a = ops.bn_forward(x, gamma, beta, rm_a, rv_a, nbt_a, True, act=act, out2_dtype=torch.bfloat16)
+
+    rm_b, rv_b, nbt_b = rm0.clone(), rv0.clone(), torch.zeros(1, dtype=torch.int64, device="cuda")
+    s, sq = ops.colsum(x, 1, rows, want_sq=True)
+    st = torch.empty((2, C), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    ops.call("mfnet_bn_finalize", s.data_ptr(), sq.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), rm_b.data_ptr(), rv_b.data_ptr(),
+             nbt_b.data_ptr(), C, rows, 1e-5, 0.1, 1, stream)
+    y_b = torch.empty_like(y_a)
+    y2_b = torch.empty_like(y2_a)
+    ops.call("mfnet_bn_apply", x.data_ptr(), 0, st[0].data_ptr(), st[1].data_ptr(), gamma.data_ptr(), beta.data_ptr(), act, None, 0,
+             y_b.data_ptr(), 0, y2_b.data_ptr(), 1, rows, C, stream)
+    torch.cuda.synchronize()
+    for a, b in ((y_a, y_b), (y2_a, y2_b), (mean_a, st[0]), (rstd_a, st[1]), (rm_a, rm_b), (rv_a, rv_b), (nbt_a, nbt_b)):
+        assert torch.equal(a, b)
+    assert int(nbt_a) == 1
+    ref = torch.nn.functional.batch_norm(x.double(), None, None, gamma.double(), beta.double(), True, 0.1, 1e-5)
+    if act == 0:
+        assert (y_a.double() - ref).abs().max().item() < 1e-4
