@@ -318,11 +318,21 @@ extern "C" int mfnet_gather_segments(const int64_t* desc, int n, int dst_dtype, 
       MF_CHECK_ARG(tot < (1ll << 31), "gather_segments: segment %d too large", base + i);
       MF_CHECK_ARG(d[14] >= 1 && d[14] <= 4096 && d[15] >= 0 && d[15] < (1ll << 31), "gather_segments: bad reduction in segment %d", base + i);
       s.red_n = (int)d[14]; s.red_stride = (int)d[15]; s.pad_ = 0;
+      if (s.red_n > 1) {
+        // a summed stack reads red_n times what it writes: walk the index space with the smallest SOURCE stride fastest
+        // (a conv weight gradient arrives as [O, kh, kw, I] tiles and leaves as [O, I, kh, kw]) - same sums, coalesced reads
+        for (int a = 1; a < 4; ++a)
+          for (int b = a; b > 0 && (s.dims[b - 1] == 1 ? 0 : s.sstr[b - 1]) < (s.dims[b] == 1 ? 0 : s.sstr[b]) ; --b) {
+            const int td = s.dims[b], ts = s.sstr[b], tt = s.dstr[b];
+            s.dims[b] = s.dims[b - 1]; s.sstr[b] = s.sstr[b - 1]; s.dstr[b] = s.dstr[b - 1];
+            s.dims[b - 1] = td; s.sstr[b - 1] = ts; s.dstr[b - 1] = tt;
+          }
+      }
       { const unsigned int bits = (unsigned int)(d[16] & 0xffffffffll); memcpy(&s.scale, &bits, 4); }
       if (i < cnt && tot * (d[14] < 16 ? d[14] : 16) > nmax) nmax = tot * (d[14] < 16 ? d[14] : 16);   // split sums: more, shorter threads
     }
     int64_t gx = ceil_div64(nmax, 256 * 8);
-    gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);       // a summed stack is latency-bound per thread: many short threads
     hipLaunchKernelGGL(gather_segments_kernel, dim3((unsigned)gx, (unsigned)cnt), dim3(256), 0, stream, p, mode);
     MF_LAUNCH_CHECK("gather_segments");
   }
