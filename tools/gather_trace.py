@@ -1,3 +1,5 @@
+"""Durations (us) of the gather_segments launches of the last captured step in a rocprofv3 kernel trace:
+   python tools/gather_trace.py <rocprof output dir>"""
 import csv,re,glob,sys
 f=glob.glob(sys.argv[1]+'/*/*_kernel_trace.csv')[0]
 rows=list(csv.DictReader(open(f)))
