@@ -34,8 +34,14 @@ extern "C" int mfnet_normalize_rgb_u8(const unsigned char* in, float* out, int64
   return MFNET_OK;
 }
 
-// numpy 'reflect' index for a tile of valid length n padded to a longer window
-__device__ __forceinline__ int reflect_idx(int i, int n) { return i < n ? i : 2 * n - 2 - i; }
+// numpy 'reflect' index for a tile of valid length n padded to a longer window: the reflection is periodic
+// (period 2n-2), so a pad longer than n-1 reflects a second time as np.pad(mode='reflect') does (inference.py:732)
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  if (i < n) return i;
+  if (n <= 1) return 0;
+  const int m = i % (2 * n - 2);
+  return m < n ? m : 2 * n - 2 - m;
+}
 // coords[t] = (row, col, valid_h, valid_w); rgb [C,H,W] fp32, dsm [H,W] fp32 -> rgb_out [n,C,h,w], dsm_out [n,h,w]
 __global__ __launch_bounds__(256) void extract_tiles_kernel(const float* __restrict__ rgb, const float* __restrict__ dsm, const int* __restrict__ coords,
                                                             float* __restrict__ rgb_out, float* __restrict__ dsm_out, int64_t n, int C, int64_t H,
@@ -55,7 +61,7 @@ __global__ __launch_bounds__(256) void extract_tiles_kernel(const float* __restr
 }
 extern "C" int mfnet_extract_tiles(const float* rgb, const float* dsm, const int* coords, float* rgb_out, float* dsm_out, int64_t n, int64_t C,
                                    int64_t H, int64_t W, int64_t h, int64_t w, hipStream_t stream) {
-  MF_CHECK_ARG(rgb && dsm && coords && rgb_out && dsm_out && C > 0 && h > 0 && w > 0, "extract_tiles: bad args");
+  MF_CHECK_ARG(rgb && dsm && coords && rgb_out && dsm_out && C > 0 && h > 0 && w > 0 && H > 0 && W > 0, "extract_tiles: bad args");
   if (n <= 0) return MFNET_OK;
   hipLaunchKernelGGL(extract_tiles_kernel, dim3(grid_for(n * (C + 1) * h * w)), dim3(256), 0, stream, rgb, dsm, coords, rgb_out, dsm_out, n, (int)C, H, W, (int)h, (int)w);
   MF_LAUNCH_CHECK("extract_tiles");

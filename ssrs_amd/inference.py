@@ -118,10 +118,31 @@ def merge_bands(band: torch.Tensor, plan, rank: int, add_rows: Callable[[torch.T
             dist.send(band[:, me["own_hi"] - me["lo"]:me["hi"] - me["lo"], :].contiguous(), dst=rank + 1, group=group)
 
 
+def _coords4(tuples, H, W, h, w, device):
+    """[(row, col, valid_h, valid_w)] -> int32 device tensor, after checking on the HOST that every window stays inside
+    the raster and its valid extent inside the tile (the extraction kernel trusts these numbers)."""
+    for r, c, vh, vw in tuples:
+        if not (0 <= r and 0 <= c and 1 <= vh <= h and 1 <= vw <= w and r + vh <= H and c + vw <= W):
+            raise ValueError(f"window (row {r}, col {c}, {vh}x{vw}) leaves the {H}x{W} raster or its {h}x{w} tile")
+    return torch.tensor(list(tuples), dtype=torch.int32, device=device)
+
+
 def _dist_info(group=None):
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(group), dist.get_world_size(group)
     return 0, 1
+
+
+def _share_owned_rows(plan, group, *rasters):
+    """Every rank ends up with the whole [H, W] rasters: rank r broadcasts the rows it owns (a partition of [0, H)), in
+    place. Each row crosses the fabric once per receiver - an all-gather of the owned bands - where an all-reduce of the
+    zero-padded full rasters moved (and summed) world times as much."""
+    for r, pl in enumerate(plan):
+        if pl["own_hi"] <= pl["own_lo"]:
+            continue
+        src = dist.get_global_rank(group, r) if group is not None else r
+        for t in rasters:
+            dist.broadcast(t[pl["own_lo"]:pl["own_hi"]], src=src, group=group)
 
 
 def _device_add_rows(band, buf):
@@ -160,7 +181,7 @@ class SlidingWindowPredictor:
         band = torch.zeros((C, max(1, me["hi"] - me["lo"]), W), dtype=torch.float32, device=img.device)
         mine = coords[me["first"]:me["last"]]
         for chunk in grouper(self.batch_size, mine):
-            c4 = torch.tensor([(r, c, h, w) for r, c in chunk], dtype=torch.int32, device=img.device)
+            c4 = _coords4([(r, c, h, w) for r, c in chunk], H, W, h, w, img.device)
             rgb_t, dsm_t = ops.extract_tiles(img, d, c4, h, w)
             logits = self.forward(rgb_t, dsm_t).float().contiguous()
             c2 = (c4[:, :2] - torch.tensor([me["lo"], 0], dtype=torch.int32, device=img.device)).contiguous()
@@ -172,7 +193,7 @@ class SlidingWindowPredictor:
         if own.shape[1] > 0:
             mask[me["own_lo"]:me["own_hi"]] = ops.argmax_chw(own)
         if world > 1:
-            dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)   # owned row ranges are disjoint
+            _share_owned_rows(plan, self.group, mask)                       # owned row ranges are disjoint: each travels once
         return (mask, (own, me["own_lo"])) if return_scores else mask
 
 
@@ -250,7 +271,7 @@ class RasterInference:
         wins = get_sliding_windows(H, W, self.window_size, self.overlap)
         per = (len(wins) + world - 1) // world
         for chunk in grouper(self.batch_size, wins[rank * per:(rank + 1) * per]):
-            c4 = torch.tensor([(y, x, ye - y, xe - x) for y, x, ye, xe in chunk], dtype=torch.int32, device=img.device)
+            c4 = _coords4([(y, x, ye - y, xe - x) for y, x, ye, xe in chunk], H, W, h, w, img.device)
             rgb_t, dem_t = ops.extract_tiles(img, demc, c4, h, w)
             ops.tile_minmax_norm(dem_t)
             logits = self.forward(rgb_t, dem_t).float().contiguous()
@@ -277,7 +298,7 @@ class RasterInference:
         band = torch.zeros((2, max(1, me["hi"] - me["lo"]), W), dtype=torch.float32, device=img.device)   # [prob sum ; count]
         demc = dem.float().contiguous()
         for chunk in grouper(self.batch_size, wins[me["first"]:me["last"]]):
-            c4 = torch.tensor([(y, x, ye - y, xe - x) for y, x, ye, xe in chunk], dtype=torch.int32, device=img.device)
+            c4 = _coords4([(y, x, ye - y, xe - x) for y, x, ye, xe in chunk], H, W, h, w, img.device)
             rgb_t, dem_t = ops.extract_tiles(img, demc, c4, h, w)              # reflect-pads short tiles
             ops.tile_minmax_norm(dem_t)                                        # per-tile DSM min-max
             logits = self.forward(rgb_t, dem_t).float().contiguous()
@@ -293,6 +314,5 @@ class RasterInference:
             p, m = ops.blend_finish(band[0, sl].contiguous(), band[1, sl].contiguous(), self.threshold)
             prob[me["own_lo"]:me["own_hi"]], mask[me["own_lo"]:me["own_hi"]] = p, m
         if world > 1:
-            dist.all_reduce(prob, op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)
+            _share_owned_rows(plan, self.group, prob, mask)
         return prob, mask

@@ -827,13 +827,20 @@ def normalize_rgb_u8(img_u8, scale=1.0 / 255.0, mean=IMAGENET_MEAN, std=IMAGENET
     return out
 
 
-def extract_tiles(rgb, dsm, coords4, h, w):
+def extract_tiles(rgb, dsm, coords4, h, w, check_extents=False):
     """rgb [C,H,W] fp32, dsm [H,W] fp32, coords4 [n,4] int32 (row, col, valid_h, valid_w) -> ([n,C,h,w], [n,h,w])."""
     _chk(rgb, dsm, coords4)
     assert rgb.is_contiguous() and dsm.is_contiguous() and rgb.dtype == dsm.dtype == torch.float32
     assert coords4.dtype == torch.int32 and coords4.is_contiguous() and coords4.shape[1] == 4
     C, H, W = rgb.shape
     n = coords4.shape[0]
+    if check_extents and n:
+        # the kernel trusts the extents (coords live on the device): row + valid_h <= H, col + valid_w <= W, 1 <= valid <= tile
+        c = coords4.cpu() if coords4.is_cuda else coords4
+        ok = ((c[:, 0] >= 0) & (c[:, 1] >= 0) & (c[:, 2] >= 1) & (c[:, 3] >= 1) & (c[:, 2] <= h) & (c[:, 3] <= w)
+              & (c[:, 0] + c[:, 2] <= H) & (c[:, 1] + c[:, 3] <= W))
+        if not bool(ok.all()):
+            raise MfnetError("extract_tiles: a window leaves the raster (row + valid_h <= H, col + valid_w <= W, 1 <= valid <= tile)")
     ro = torch.empty((n, C, h, w), dtype=torch.float32, device=rgb.device)
     do = torch.empty((n, h, w), dtype=torch.float32, device=rgb.device)
     call("mfnet_extract_tiles", rgb.data_ptr(), dsm.data_ptr(), coords4.data_ptr(), ro.data_ptr(), do.data_ptr(), n, C, H, W, h, w, _stream(rgb))

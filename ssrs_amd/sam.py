@@ -153,7 +153,7 @@ def _build_sam(args, encoder_embed_dim, encoder_depth, encoder_num_heads, encode
             raise FileNotFoundError(f"SAM checkpoint {checkpoint} not found (download it beforehand; the "
                                     "reference's interactive download is not reproduced)")
         with open(checkpoint, "rb") as f:
-            state_dict = torch.load(f, map_location="cpu")
+            state_dict = torch.load(f, map_location="cpu", weights_only=True)
         own = sam.state_dict()
         keep = {k: v for k, v in state_dict.items() if k in own and own[k].shape == v.shape}
         sam.load_state_dict(keep, strict=False)

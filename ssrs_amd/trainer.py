@@ -127,8 +127,13 @@ class TrainEngine:
                 v.copy_(p.data)
                 p.data = v
                 p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+        if self.world > 1:
+            # identical replicas from the start (what DDP's constructor does): rank 0's parameters and BatchNorm buffers
+            # replace whatever the other ranks initialised, so averaged gradients keep the replicas identical
+            self.broadcast_state()
         self._pending = [0] * len(self.bucket_bounds)
         self._works = []
+        self._launched = [False] * len(self.bucket_bounds)
         self._bucket_size = [self.bucket_of.count(b) for b in range(len(self.bucket_bounds))]
         self._hooks = []
         # Gradients are added into flat_g by the modules' backward passes themselves (bank.deliver: one gather
@@ -162,8 +167,21 @@ class TrainEngine:
                 self._launch(b)
         return hook
 
+    def broadcast_state(self, src: int = 0):
+        """Rank `src`'s trainable parameters and every floating / integer buffer (BatchNorm running statistics,
+        num_batches_tracked) go to all ranks: called at construction and before a checkpoint is written (per-replica
+        BatchNorm statistics differ between ranks; the saved model carries rank `src`'s)."""
+        if self.world == 1:
+            return
+        root = dist.get_global_rank(self.pg, src) if self.pg is not None else src
+        dist.broadcast(self.flat_p, src=root, group=self.pg)
+        for b in self.model.buffers():
+            if b.numel():
+                dist.broadcast(b, src=root, group=self.pg)
+
     def _launch(self, b):
         lo, hi = self.bucket_bounds[b]
+        self._launched[b] = True
         self._works.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def _finish_exchange(self):
@@ -173,15 +191,17 @@ class TrainEngine:
             # nothing to overlap with (graph replay / overlap off): ONE all-reduce over the whole flat gradient buffer -
             # every collective costs a launch and a stream hand-off of its own
             self._works.append(dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-        elif any(c != s for c, s in zip(self._pending, self._bucket_size)):
-            # a bucket whose hooks did not all fire (a tensor without gradient this step) is reduced whole
-            done = len(self._works)
-            for b in range(done, len(self.bucket_bounds)):
-                self._launch(b)
+        else:
+            # a bucket whose hooks did not all fire (a tensor without gradient this step) is reduced whole; exactly the
+            # buckets that have not been launched yet, whatever order the others went in
+            for b in range(len(self.bucket_bounds)):
+                if not self._launched[b]:
+                    self._launch(b)
         for w in self._works:
             w.wait()                      # stream-level wait: the compute stream waits for RCCL, the host does not
         self._works.clear()
         self._pending = [0] * len(self.bucket_bounds)
+        self._launched = [False] * len(self.bucket_bounds)
 
     # ---- one step
     def zero_grad(self):
@@ -343,7 +363,8 @@ class Trainer:
     def __init__(self, model_wrapper: ModelWrapper, evaluator=None, *, train_loader: Iterable = None,
                  training: Optional[TrainingConfig] = None, epochs: int = 50, save_epoch: int = 1,
                  ignore_index: int = -100, skip_empty: bool = False, output_dir: str = "./results/",
-                 model_name: str = "UNetformer", sync_every: int = 10, validate_fn=None):
+                 model_name: str = "UNetformer", sync_every: int = 10, validate_fn=None, val_samples=None, test_ids=None,
+                 val_stride: int = 32):
         self.model_wrapper = model_wrapper
         self.model = model_wrapper.get_model()
         self.evaluator = evaluator
@@ -355,6 +376,9 @@ class Trainer:
         self.output_dir, self.model_name = output_dir, model_name
         self.sync_every = max(1, int(sync_every))
         self.validate_fn = validate_fn
+        self.val_samples, self.test_ids, self.val_stride = val_samples, test_ids, val_stride
+        if evaluator is not None and validate_fn is None and val_samples is None and test_ids is None:
+            raise ValueError("Trainer: an evaluator needs its validation inputs - val_samples= or test_ids= (or give validate_fn=)")
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         dev = next(self.model.parameters()).device
         t = self.training
@@ -381,29 +405,37 @@ class Trainer:
         pend = torch.zeros(4, device=dev)
         epoch_acc = torch.zeros(4, device=dev)
         nb = 0
+        multi = dist.is_initialized() and dist.get_world_size() > 1
         for batch_idx, (data, dsm, target) in enumerate(self.train_loader):
             data = data.to(dev, non_blocking=True)
             dsm = dsm.to(dev, non_blocking=True)
             target = target.to(dev, non_blocking=True)
             if self.skip_empty:
+                # train_multiscale_main.py:113-125. Under data parallelism the decision is COLLECTIVE: a step is skipped
+                # only when every rank's batch is empty, so all ranks issue the same gradient collectives.
                 valid = target[target != 255]
-                if valid.numel() == 0 or bool(torch.all(valid == 0)):
+                empty = torch.tensor([1 if (valid.numel() == 0 or bool(torch.all(valid == 0))) else 0], device=dev, dtype=torch.int32)
+                if multi:
+                    dist.all_reduce(empty, op=dist.ReduceOp.MIN)
+                if int(empty.item()):
                     continue
             acc = self.engine.step(data, dsm, target)
             pend += acc
             epoch_acc += acc
             nb += 1
-            if nb % self.sync_every == 0:
+            # metric syncs follow batch_idx (equal on every rank given equal loader lengths), never a per-rank count
+            if (batch_idx + 1) % self.sync_every == 0:
                 m = TrainEngine.read_metrics(self._reduce(pend))
                 pend.zero_()
-                self.losses.append(m["loss"])
-                self.recent_losses = (self.recent_losses + [m["loss"]])[-self.loss_trend_window:]
-                self.recent_accuracies = (self.recent_accuracies + [m["accuracy"]])[-self.loss_trend_window:]
-                if self.rank == 0:
-                    print(f"\rEpoch {epoch:2d}/{self.epochs} {batch_idx:4d} | Loss: {m['loss']:7.4f} | "
-                          f"Acc: {m['accuracy']:5.1f}% | LR: {self.engine.lr:.2e}", end="")
-                self._check_early_overfitting_signs()
-        m = TrainEngine.read_metrics(self._reduce(epoch_acc)) if nb else {"loss": float("nan")}
+                if m["loss"] == m["loss"]:
+                    self.losses.append(m["loss"])
+                    self.recent_losses = (self.recent_losses + [m["loss"]])[-self.loss_trend_window:]
+                    self.recent_accuracies = (self.recent_accuracies + [m["accuracy"]])[-self.loss_trend_window:]
+                    if self.rank == 0:
+                        print(f"\rEpoch {epoch:2d}/{self.epochs} {batch_idx:4d} | Loss: {m['loss']:7.4f} | "
+                              f"Acc: {m['accuracy']:5.1f}% | LR: {self.engine.lr:.2e}", end="")
+                    self._check_early_overfitting_signs()
+        m = TrainEngine.read_metrics(self._reduce(epoch_acc))
         if self.rank == 0:
             print()
         return {"avg_loss": m["loss"], "training_time": time.time() - start}
@@ -415,12 +447,23 @@ class Trainer:
             raise KeyboardInterrupt("auto-stop: recent training accuracy above 99 %")
 
     def validate(self, epoch: int) -> float:
+        """trainer.py:345-377. `validate_fn(model_wrapper)` wins if given; otherwise the evaluator is called the way its
+        interface asks: the drop-in `ssrs_amd.inference.Evaluator` with the in-memory `val_samples` (and `val_stride`), an
+        evaluator with the reference's file-based signature with `test_ids=` / `stride=` (evaluator.py:178-230)."""
         if self.validate_fn is None and self.evaluator is None:
             print("No evaluator provided, skipping validation")
             return 0.0
         self.model.eval()
         try:
-            miou = self.validate_fn(self.model_wrapper) if self.validate_fn else self.evaluator.evaluate(self.model_wrapper)
+            if self.validate_fn is not None:
+                miou = self.validate_fn(self.model_wrapper)
+            elif self.val_samples is not None:
+                miou = self.evaluator.evaluate(self.model_wrapper, self.val_samples, stride=self.val_stride)
+            elif self.test_ids is not None:
+                miou = self.evaluator.evaluate(self.model_wrapper, test_ids=self.test_ids, stride=self.val_stride)
+            else:
+                raise ValueError("Trainer.validate: pass val_samples= (in-memory rasters for ssrs_amd.inference.Evaluator), "
+                                 "test_ids= (an evaluator with the reference's signature) or validate_fn= to Trainer")
         finally:
             self.model.train()
         return float(miou)
@@ -428,6 +471,7 @@ class Trainer:
     def save_checkpoint(self, epoch: int, miou: float) -> None:
         if miou > self.best_miou:
             self.best_miou = miou
+            self.engine.broadcast_state()          # rank 0's BatchNorm running statistics become everybody's
             if self.rank == 0:
                 import os
                 os.makedirs(self.output_dir, exist_ok=True)

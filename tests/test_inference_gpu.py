@@ -346,3 +346,70 @@ def test_device_input_pipeline_matches_numpy_reference_order():
         assert np.array_equal(out[2][t].cpu().numpy(), l)
     c2 = random_codes(4096, torch.Generator().manual_seed(1))
     assert c2.dtype == torch.int32 and int(c2.max()) < 16 and abs(((c2 >> 2) == 0).float().mean().item() - 0.5) < 0.05
+
+
+# ------------------------------------------------------------------------------------------ pre / post steps vs the REFERENCE's outputs
+def test_normalize_raster_vs_reference_golden():
+    """mfnet_normalize_raster against BuildingInference._normalize_image itself (prepost.npz): bit-equal for the integer
+    rasters; the fp32 percentile-stretch cases to fp32 rounding (the fixture ran those statements in float64 under numpy 2.2)."""
+    from golden_inputs import prepost_inputs
+    from ssrs_amd import ops
+    g = golden("prepost")
+    for k, (img, is_rgb, nd) in enumerate(prepost_inputs()):
+        t = torch.from_numpy(img.view(np.int16)).view(torch.uint16) if img.dtype == np.uint16 else torch.from_numpy(img)
+        out, mask = ops.normalize_raster(t.cuda(), is_rgb, nd)
+        want = g[f"norm{k}_out"]
+        assert np.array_equal(mask.cpu().numpy(), g[f"norm{k}_mask"]), k
+        if want.dtype == np.float32:
+            assert np.array_equal(out.cpu().numpy(), want), (k, np.abs(out.cpu().numpy() - want).max())
+        else:
+            assert np.abs(out.cpu().numpy() - want).max() < 2e-6, k
+
+
+def test_tile_probabilities_vs_reference_golden():
+    """RasterInference.predict_tiles against the per-tile probabilities the reference's own tile loop hands to its vectoriser
+    (_tile_by_tile_vector_inference + _predict_patch, prepost.npz), incl. the raster that is window/2 high (reflected twice)
+    and the constant-elevation tile."""
+    from golden_inputs import prepost_rasters, standin_model
+    from ssrs_amd.inference import RasterInference
+    g = golden("prepost")
+    for name, rgb, dem in prepost_rasters():
+        ri = RasterInference(standin_model, (64, 64), overlap_ratio=0.5, batch_size=5, threshold=0.5)
+        got = list(ri.predict_tiles(torch.from_numpy(rgb).cuda(), torch.from_numpy(dem).cuda(), want_prob=True))
+        wins = g[f"tiles_{name}_windows"]
+        assert [tuple(w) for w, _, _ in got] == [tuple(int(v) for v in w) for w in wins], name
+        for i, (_, mask, prob) in enumerate(got):
+            want = g[f"tiles_{name}_prob{i}"]
+            assert prob.shape == want.shape and np.abs(prob - want).max() < 1e-5, (name, i, np.abs(prob - want).max())
+            sure = np.abs(want - 0.5) > 1e-5
+            assert np.array_equal(mask[sure], (want >= 0.5)[sure].astype(np.uint8))
+
+
+def test_extract_tiles_rejects_windows_that_leave_the_raster():
+    from ssrs_amd import ops
+    from ssrs_amd._lib import MfnetError
+    from ssrs_amd.inference import _coords4
+    with pytest.raises(ValueError):
+        _coords4([(0, 0, 33, 10)], 32, 50, 64, 64, "cpu")
+    rgb, dsm = torch.zeros(3, 32, 50, device="cuda"), torch.zeros(32, 50, device="cuda")
+    with pytest.raises(MfnetError):
+        ops.extract_tiles(rgb, dsm, torch.tensor([[0, 0, 33, 10]], dtype=torch.int32, device="cuda"), 64, 64, check_extents=True)
+
+
+def test_device_input_pipeline_vs_reference_golden():
+    """DeviceAugment against MultiScaleSegmentationDataset.__getitem__ itself (prepost.npz): the 16 flip / rot90 codes, ImageNet
+    normalisation, per-patch DSM min-max with the flat patch left as it is."""
+    from golden_inputs import multiscale_inputs
+    from ssrs_amd.data import DeviceAugment
+    g = golden("prepost")
+    S, rgb, dsm, lab = multiscale_inputs()
+    tiles = [(rgb[:, (c // 8) * S:(c // 8) * S + S, (c % 8) * S:(c % 8) * S + S], dsm[(c // 8) * S:(c // 8) * S + S, (c % 8) * S:(c % 8) * S + S],
+              lab[(c // 8) * S:(c // 8) * S + S, (c % 8) * S:(c % 8) * S + S]) for c in range(16)]
+    r = torch.from_numpy(np.stack([t[0] for t in tiles])).cuda()
+    d = torch.from_numpy(np.stack([t[1] for t in tiles])).cuda()
+    l = torch.from_numpy(np.stack([t[2] for t in tiles])).cuda()
+    out = DeviceAugment()(r, d, l, torch.arange(16, dtype=torch.int32))
+    for c in range(16):
+        assert np.abs(out[0][c].cpu().numpy() - g[f"msd{c}_rgb"]).max() < 2e-6, c
+        assert np.abs(out[1][c].cpu().numpy() - g[f"msd{c}_dsm"]).max() < 1e-6, c
+        assert np.array_equal(out[2][c].cpu().numpy(), g[f"msd{c}_lab"].astype(np.int64)), c

@@ -196,3 +196,80 @@ def test_metrics_match_reference():
     gt[::3] = p[::3]
     m = R.confusion_metrics(p, gt, 6)
     assert abs(m["mIoU"] - float(golden("metrics")["miou"])) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------ pre / post steps (prepost.npz)
+def test_normalize_image_restatement_vs_reference():
+    """R.normalize_image against BuildingInference._normalize_image itself (inference.py:444-496) on the seven dtype /
+    nodata cases. Integer inputs: bit-equal. The fp32 percentile-stretch cases (3, 4): the fixture was produced under
+    numpy 2.2, whose promotion rules run those statements in float64 (np.float64 percentiles meet an fp32 array), while
+    the restatement follows numpy 1.24 - the reference's pin - and stays in fp32: equal to fp32 rounding."""
+    from golden_inputs import prepost_inputs
+    g = golden("prepost")
+    for k, (img, is_rgb, nd) in enumerate(prepost_inputs()):
+        out, mask = R.normalize_image(img, is_rgb, nd)
+        assert np.array_equal(mask, g[f"norm{k}_mask"]), k
+        want = g[f"norm{k}_out"]
+        assert out.dtype == np.float32 and out.shape == want.shape
+        if want.dtype == np.float32:
+            assert np.array_equal(out, want), (k, np.abs(out - want).max())
+        else:
+            assert k in (3, 4) and np.abs(out - want).max() < 2e-6, (k, np.abs(out - want).max())
+
+
+def test_tile_loop_restatement_vs_reference():
+    """R.tile_vector_masks against _tile_by_tile_vector_inference + _predict_patch (inference.py:687-767, 535-568): window
+    list, reflect padding (twice-reflected on the raster that is window/2 high), per-tile DEM min-max with the constant-
+    elevation fallback, softmax class-1 probability, crop."""
+    from golden_inputs import prepost_rasters, standin_model
+    g = golden("prepost")
+    for name, rgb, dem in prepost_rasters():
+        ref = R.tile_vector_masks(standin_model, R.normalize_image(rgb, True, None)[0], dem, (64, 64), 32, 0.5, 1)
+        wins = g[f"tiles_{name}_windows"]
+        assert [tuple(w) for w, _, _ in ref] == [tuple(int(v) for v in w) for w in wins], name
+        for i, (_, prob, mask) in enumerate(ref):
+            want = g[f"tiles_{name}_prob{i}"]
+            assert prob.shape == want.shape and np.abs(prob - want).max() < 1e-6, (name, i, np.abs(prob - want).max())
+            assert np.array_equal(mask[np.abs(want - 0.5) > 1e-6], (want >= 0.5)[np.abs(want - 0.5) > 1e-6])
+
+
+def test_dataset_patch_pipeline_restatement_vs_reference():
+    """R.augment_patch + R.normalise_patch against MultiScaleSegmentationDataset.__getitem__ / _apply_augmentation
+    (multiscale_dataset.py:155-245) for all 16 flip / rot90 codes, incl. the flat-DSM patch that keeps its values."""
+    from golden_inputs import multiscale_inputs
+    g = golden("prepost")
+    S, rgb, dsm, lab = multiscale_inputs()
+    for code in range(16):
+        r0, c0 = (code // 8) * S, (code % 8) * S
+        a, z, l = R.augment_patch(rgb[:, r0:r0 + S, c0:c0 + S], dsm[r0:r0 + S, c0:c0 + S], lab[r0:r0 + S, c0:c0 + S],
+                                  code & 1, (code >> 1) & 1, (code >> 2) & 3)
+        a, z = R.normalise_patch(a, z)
+        assert np.abs(a - g[f"msd{code}_rgb"]).max() < 1e-6, code
+        assert np.abs(z - g[f"msd{code}_dsm"]).max() < 1e-6, code
+        assert np.array_equal(l, g[f"msd{code}_lab"].astype(np.int64)), code
+    assert float(g["msd8_dsm"].max()) == 7.0 and float(g["msd8_dsm"].min()) == 7.0
+
+
+def test_state_dict_layout_matches_reference():
+    """The drop-in's ViT-B state dict is key-for-key the reference's (1088 keys MMLoRA / 1136 MMAdapter, same order, shapes and
+    dtypes; the encoder under `sam.image_encoder.*` and `image_encoder.*`, SAM's unused heads included) and a checkpoint in
+    that layout loads strictly (inference.py:167-173)."""
+    import argparse
+    import json
+    import os
+    import warnings
+    from helpers import GOLD
+    from ssrs_amd.unetformer_mmsam import UNetFormer
+    for mod, nkeys in (("sam_lora", 1088), ("sam_adpt", 1136)):
+        with open(os.path.join(GOLD, f"state_dict_vitb_{mod}.json")) as f:
+            want = json.load(f)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = UNetFormer(num_classes=6, encoder="vit_b", args=argparse.Namespace(mod=mod, mid_dim=None, image_size=1024, multimask_output=1))
+        sd = m.state_dict()
+        assert len(want) == nkeys and list(sd.keys()) == list(want.keys()), mod
+        for k, v in sd.items():
+            assert [list(v.shape), str(v.dtype)] == want[k], (mod, k)
+        # strict load of a checkpoint written in the reference's layout
+        ck = {k: torch.zeros(shape, dtype=getattr(torch, dt.split(".")[1])) for k, (shape, dt) in want.items()}
+        m.load_state_dict(ck, strict=True)

@@ -20,7 +20,9 @@ import torch.nn as nn
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
 from ssrs_amd import detfill  # noqa: E402
+from golden_inputs import multiscale_inputs, prepost_inputs, prepost_rasters, standin_model  # noqa: E402
 
 REF = "/root/reference"
 GOLD = os.path.join(REPO, "tests", "golden")
@@ -300,7 +302,81 @@ def case_metrics():
     save("metrics", miou=np.array(miou))
 
 
-CASES = dict(blocks=case_blocks, encoder=case_encoder, model_tiny=case_model_tiny,
+def case_state_dict():
+    """Key order, shapes and dtypes of the reference's ViT-B state dict for both mods (1088 / 1136 keys, the encoder under
+    two names, SAM's unused heads included) - the layout `inference.py:167-173` loads strictly."""
+    import json
+    for mod in ("sam_lora", "sam_adpt"):
+        m = _build_model(mod, "vit_b")
+        layout = {k: [list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()}
+        path = os.path.join(GOLD, f"state_dict_vitb_{mod}.json")
+        with open(path, "w") as f:
+            json.dump(layout, f)
+        print(f"  wrote {path}  ({len(layout)} keys)")
+
+
+def case_prepost():
+    """The reference's own pre / post steps around the two loops, called UNBOUND on stand-in `self` objects (the geo
+    libraries they sit beside are stubs; none of the called statements touches them):
+      BuildingInference._normalize_image (inference.py:444-496), ._tile_by_tile_vector_inference + ._predict_patch
+      (:687-767, :535-568; the per-tile probabilities it hands to the vectoriser), MultiScaleSegmentationDataset.__getitem__
+      + ._apply_augmentation (multiscale_dataset.py:155-245) for all 16 flip / rot90 codes with a scripted `random`."""
+    import inference
+    BI = inference.BuildingInference
+    arrs = {}
+    for k, (img, is_rgb, nd) in enumerate(prepost_inputs()):
+        out, mask = BI._normalize_image(None, img, is_rgb, nd)
+        arrs[f"norm{k}_out"] = out
+        arrs[f"norm{k}_mask"] = mask
+    # tile loop
+    class Affine:
+        def __init__(self, *a):
+            self.a, self.b, self.c, self.d, self.e, self.f = a
+    inference.rasterio.Affine = Affine
+    for name, rgb, dem in prepost_rasters():
+        preds = []
+        ns = types.SimpleNamespace(window_size=(64, 64), overlap=32, overlap_ratio=0.5, debug_tiles=False, debug_dir="", device="cpu",
+                                   model=standin_model)
+        ns._get_sliding_windows = lambda h, w, ns=ns: BI._get_sliding_windows(ns, h, w)
+        ns._predict_patch = lambda a, b, ns=ns: BI._predict_patch(ns, a, b)
+        ns._create_tile_vectors = lambda pred, tf, crs: preds.append(pred.copy()) or []
+        ns._save_debug_tile = lambda *a, **k: None
+        img, _ = BI._normalize_image(None, rgb, True, None)
+        BI._tile_by_tile_vector_inference(ns, img, dem[None], Affine(1.0, 0.0, 0.0, 0.0, -1.0, 0.0), "crs")
+        wins = BI._get_sliding_windows(ns, rgb.shape[1], rgb.shape[2])
+        assert len(wins) == len(preds)
+        arrs[f"tiles_{name}_windows"] = np.array(wins)
+        for i, p_ in enumerate(preds):
+            arrs[f"tiles_{name}_prob{i}"] = p_
+    # dataset patch pipeline
+    _stub("skimage.transform", resize=None)
+    sys.modules["skimage"].transform = sys.modules["skimage.transform"]
+    import multiscale_dataset as MS
+    DS = MS.MultiScaleSegmentationDataset
+    S, rgb, dsm, lab = multiscale_inputs()
+
+    class Scripted:
+        def __init__(self, seq, k):
+            self.seq, self.k = list(seq), k
+        def random(self):
+            return self.seq.pop(0)
+        def randint(self, a, b):
+            return self.k
+        def uniform(self, a, b):
+            raise AssertionError("brightness / scale branches are scripted off")
+    ns = types.SimpleNamespace(tile_ids=["t"], window_size=(S, S), stride_size=S, augment=True, mean=np.array([0.485, 0.456, 0.406]),
+                               std=np.array([0.229, 0.224, 0.225]), _load_tile_data=lambda tid: (rgb, dsm, lab))
+    ns._apply_augmentation = lambda a, b, c: DS._apply_augmentation(ns, a, b, c)
+    for code in range(16):
+        hf, vf, k = code & 1, (code >> 1) & 1, (code >> 2) & 3
+        MS.random = Scripted([0.9 if hf else 0.1, 0.9 if vf else 0.1, 0.9 if k else 0.1, 0.1, 0.1], k)
+        r, d, l = DS.__getitem__(ns, code)               # patch index = code (one 256-px tile holds 64 patches of 32 px)
+        assert not MS.random.seq
+        arrs[f"msd{code}_rgb"], arrs[f"msd{code}_dsm"], arrs[f"msd{code}_lab"] = r, d, l.to(torch.uint8)
+    save("prepost", **arrs)
+
+
+CASES = dict(state_dict=case_state_dict, prepost=case_prepost, blocks=case_blocks, encoder=case_encoder, model_tiny=case_model_tiny,
              model_vitb=case_model_vitb, sliding=case_sliding, metrics=case_metrics)
 
 if __name__ == "__main__":
