@@ -224,6 +224,16 @@ int mfnet_scale_shift(const float* x, float* y, const float* mm, float unused, i
 int64_t mfnet_colreduce_workspace_floats(int64_t G, int64_t P, int64_t C);
 int mfnet_colsum(const void* x, int x_dtype, float* sum, float* sumsq, int64_t G, int64_t P, int64_t C,
                  float* workspace, unsigned int* tickets, hipStream_t stream);
+/* mfnet_colsum without a workspace argument, for callers that cannot allocate: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc. It has NO counterpart in the reference (neither has mfnet_colsum's workspace: the
+ * reference's sums are ATen reductions) - it exists for those callers only. Same kernels and bit-identical results; the partial
+ * slabs and tickets live in a file-scope device array of the library (4 MiB + 4 KiB per GPU the library runs on, held until
+ * the process ends). Limits: mfnet_colreduce_workspace_floats(G, P, C) <= 1048576 floats and G <= 1024, else MFNET_ERR_ARG
+ * (every BatchNorm / SE / FRH reduction of MFNet at 16 tiles per GPU fits). It calls no hipMalloc / hipFree; the tickets are
+ * cleared by a hipMemsetAsync on `stream`. All calls on one GPU share that GPU's array: calls that overlap in time on one
+ * GPU (different streams, different threads) race - serialise them on one stream. The first call on each device looks the
+ * array's address up (hipGetSymbolAddress): make it outside any stream capture. */
+int mfnet_colsum_static(const void* x, int x_dtype, float* sum, float* sumsq, int64_t G, int64_t P, int64_t C, hipStream_t stream);
 int mfnet_coldot(const void* a, int a_dtype, const void* b, int b_dtype, float* out, int64_t G, int64_t P, int64_t C,
                  float* workspace, unsigned int* tickets, hipStream_t stream);
 /* LayerNorm weight gradients, deterministic: dbeta [C] += sum_rows dy ; dgamma [C] += sum_rows dy * (x - mean[row]) * rstd[row]

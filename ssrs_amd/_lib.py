@@ -65,6 +65,7 @@ _SIGS = {
     "mfnet_gemm_tn_bf16_grouped": [P, I64, P, I64, I64, I64, I64, P, I64, I, I, P],
     # ---- FPN / SE-fusion / UNetFormer decoder (csrc/decoder.hip)
     "mfnet_colsum": [P, I, P, P, I64, I64, I64, P, P, P],
+    "mfnet_colsum_static": [P, I, P, P, I64, I64, I64, P],
     "mfnet_coldot": [P, I, P, I, P, I64, I64, I64, P, P, P],
     "mfnet_layernorm_bwd_weights": [P, I, P, I, P, P, P, P, I64, I64, P, P, P],
     "mfnet_bn_finalize": [P, P, P, P, P, P, P, I64, I64, F, F, I, P],

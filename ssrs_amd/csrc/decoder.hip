@@ -15,6 +15,7 @@
 //   up_final_* : bilinear x4 of the class maps into NCHW logits, and its adjoint
 //   maxpool2_*, se_*, frh_gate_* : fpn4, SqueezeAndExcitation / SEFusion, FRH pixel+channel attention
 #include "common.h"
+#include <mutex>
 #include <stdlib.h>
 #include <float.h>
 
@@ -300,6 +301,57 @@ extern "C" int mfnet_colsum(const void* x, int x_dtype, float* sum, float* sumsq
   p.a = x; p.a_dt = x_dtype; p.out0 = sum; p.out1 = sumsq; p.P = P; p.C = (int)C; p.mode = 0;
   return launch_colreduce(p, G, workspace, tickets, stream, "colsum");
 }
+// ---- mfnet_colsum for callers that cannot allocate (HIP graph capture, tight serving loops, harnesses that forbid
+// hipMalloc): the same kernels, with the partial slabs and the tickets in a file-scope device array instead of a
+// caller workspace. `scratch` is a host-side stand-in in host code, never a device address: its per-device address is
+// taken ONCE per device with hipGetSymbolAddress and only that pointer is handed to kernels / hipMemsetAsync.
+#define COLSUM_STATIC_MAX_FLOATS (1 << 20)     /* 4 MiB of partial slabs: G * splits * 2 * C floats */
+#define COLSUM_STATIC_MAX_GROUPS 1024          /* tickets, one per group */
+#define COLSUM_STATIC_MAX_DEVICES 64
+static __device__ __align__(256) float scratch[COLSUM_STATIC_MAX_FLOATS + COLSUM_STATIC_MAX_GROUPS];
+static float* g_scratch_ptr[COLSUM_STATIC_MAX_DEVICES];        // per device: each GPU holds its own copy at its own address
+static std::mutex g_scratch_mu;
+
+extern "C" int mfnet_colsum_static(const void* x, int x_dtype, float* sum, float* sumsq, int64_t G, int64_t P, int64_t C, hipStream_t stream) {
+  MF_CHECK_ARG(x && sum, "colsum_static: null pointer");
+  MF_CHECK_ARG(G > 0 && P > 0 && C > 0 && C % 4 == 0 && C <= 1024, "colsum_static: bad shape (C a multiple of 4, at most 1024)");
+  const int64_t need = mfnet_colreduce_workspace_floats(G, P, C);
+  MF_CHECK_ARG(G <= COLSUM_STATIC_MAX_GROUPS && need > 0 && need <= COLSUM_STATIC_MAX_FLOATS,
+               "colsum_static: G=%lld P=%lld C=%lld needs %lld floats of partial sums / %lld tickets, the static scratch holds %d / %d - "
+               "use mfnet_colsum with a caller workspace", (long long)G, (long long)P, (long long)C, (long long)need, (long long)G,
+               COLSUM_STATIC_MAX_FLOATS, COLSUM_STATIC_MAX_GROUPS);
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= COLSUM_STATIC_MAX_DEVICES) {
+    mfnet_set_error("colsum_static: no current device (or device index >= %d)", COLSUM_STATIC_MAX_DEVICES);
+    return MFNET_ERR_HIP;
+  }
+  float* ptr;
+  {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    ptr = g_scratch_ptr[dev];
+    if (!ptr) {          // set-up, once per device, with that device current
+      void* sym = nullptr;
+      const hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));
+      if (e != hipSuccess || !sym) {
+        mfnet_set_error("colsum_static: hipGetSymbolAddress(scratch) failed on device %d: %s", dev, hipGetErrorString(e));
+        return MFNET_ERR_HIP;
+      }
+      ptr = g_scratch_ptr[dev] = (float*)sym;
+    }
+  }
+  unsigned int* tickets = (unsigned int*)(ptr + COLSUM_STATIC_MAX_FLOATS);
+  // the array keeps the last call's contents: the slabs are fully rewritten before they are read, the tickets must start at
+  // zero - cleared here by a memset node on the caller's stream (a whole number of 16-byte units from a 256-byte-aligned start)
+  const hipError_t e = hipMemsetAsync(tickets, 0, (size_t)((G + 3) / 4 * 4) * sizeof(unsigned int), stream);
+  if (e != hipSuccess) {
+    mfnet_set_error("colsum_static: clearing the tickets failed: %s", hipGetErrorString(e));
+    return MFNET_ERR_HIP;
+  }
+  ColRedParams p = {};
+  p.a = x; p.a_dt = x_dtype; p.out0 = sum; p.out1 = sumsq; p.P = P; p.C = (int)C; p.mode = 0;
+  return launch_colreduce(p, G, ptr, tickets, stream, "colsum_static");
+}
+
 // out [G, C] += sum_p a[g,p,c] * b[g,p,c]
 extern "C" int mfnet_coldot(const void* a, int a_dtype, const void* b, int b_dtype, float* out, int64_t G, int64_t P, int64_t C,
                             float* workspace, unsigned int* tickets, hipStream_t stream) {

@@ -1,0 +1,48 @@
+"""The entry point that allocates nothing (mfnet_colsum_static): called through the C ABI, checked against mfnet_colsum (the
+existing entry point with a caller workspace) bit for bit, on two calls in a row, the second with a smaller input - the
+static scratch keeps the first call's slabs and the tickets must have been cleared."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(x, G, P, C, want_sq):
+    from ssrs_amd import _lib
+    from ssrs_amd._lib import BF16, F32
+    dt = BF16 if x.dtype == torch.bfloat16 else F32
+    st = torch.cuda.current_stream().cuda_stream
+    ref = torch.zeros((2, G, C), dtype=torch.float32, device="cuda")
+    nws = int(_lib.lib().mfnet_colreduce_workspace_floats(G, P, C))
+    ws = torch.empty(nws, dtype=torch.float32, device="cuda")
+    tk = torch.zeros(G, dtype=torch.int32, device="cuda")
+    _lib.call("mfnet_colsum", x.data_ptr(), dt, ref[0].data_ptr(), ref[1].data_ptr() if want_sq else None, G, P, C, ws.data_ptr(), tk.data_ptr(), st)
+    got = torch.zeros((2, G, C), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
+    _lib.call("mfnet_colsum_static", x.data_ptr(), dt, got[0].data_ptr(), got[1].data_ptr() if want_sq else None, G, P, C, st)
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated() == before
+    return got, ref
+
+
+def test_colsum_static_matches_colsum_on_two_calls_in_a_row():
+    from ssrs_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(5)
+    # first call: a large map (16 groups x 4096 rows x 256 channels, bf16: the SE pool of the 64x64 FPN level)
+    x1 = torch.randn((16 * 4096, 256), generator=g, device="cuda").to(torch.bfloat16)
+    got, ref = _both(x1, 16, 4096, 256, True)
+    assert torch.equal(got, ref) and ref[0].abs().sum() > 0
+    # second call right after it: a smaller fp32 map with fewer groups, splits and channels (BatchNorm statistics)
+    x2 = torch.randn((3 * 500, 64), generator=g, device="cuda")
+    got, ref = _both(x2, 3, 500, 64, True)
+    assert torch.equal(got, ref)
+    assert torch.allclose(ref[0], x2.view(3, 500, 64).sum(1), rtol=1e-4, atol=1e-3)
+    # and again the large one, sums only
+    got, ref = _both(x1, 16, 4096, 256, False)
+    assert torch.equal(got, ref) and float(got[1].abs().sum()) == 0.0
+    # sizes beyond the static scratch are refused with a clear message, nothing is launched
+    big = torch.empty((2048 * 8, 1024), dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros((2048, 1024), dtype=torch.float32, device="cuda")
+    with pytest.raises(_lib.MfnetError, match="static scratch"):
+        _lib.call("mfnet_colsum_static", big.data_ptr(), 1, out.data_ptr(), None, 2048, 8, 1024, torch.cuda.current_stream().cuda_stream)
