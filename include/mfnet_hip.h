@@ -72,6 +72,15 @@ int mfnet_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int6
                     int64_t rows_per_group, int n_groups, int R, float lr_scale, int act, const void* aux,
                     int64_t ldaux, void* out_pre, int64_t ldpre, const float* residual, int64_t ldres,
                     int64_t res_row_mod, void* out, int out_dtype, int64_t ldc, int k_splits, hipStream_t stream);
+/* The same call with the tile shape named by the caller (benchmarks and tests; the reference has no counterpart - its GEMMs are
+ * ATen's): tile 0 = the library's choice (what mfnet_gemm_bf16 does), -1 = the 128x128-tile kernel (2 workgroups / CU), 3 / 4 / 6 /
+ * 8 / 9 = the 256 x (32*tile)-tile kernel (one 8-wave workgroup / CU, 2-3 stage LDS ring; needs M % 256 == 0, K % 64 == 0,
+ * N % (32*tile) == 0, k_splits == 1, else MFNET_ERR_ARG). */
+int mfnet_gemm_bf16_tiled(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int64_t N, int64_t K,
+                    const float* bias, const float* U, int64_t ldu, const float* V, int64_t v_group_stride,
+                    int64_t rows_per_group, int n_groups, int R, float lr_scale, int act, const void* aux,
+                    int64_t ldaux, void* out_pre, int64_t ldpre, const float* residual, int64_t ldres,
+                    int64_t res_row_mod, void* out, int out_dtype, int64_t ldc, int k_splits, int tile, hipStream_t stream);
 /* The same GEMM with per-group weights: rows [g*rows_per_group, (g+1)*rows_per_group) (g cyclic over n_groups) use
  * W + g*w_group_stride and bias + g*bias_group_stride (elements; multiples of 8 / 4). One launch for the per-modality
  * dense layers of the MMAdapter block - Img_Adapter / DSM_Adapter and MLPx_ / MLPy_Adapter, adapter.py:16-25 applied at

@@ -33,6 +33,8 @@ _SIGS = {
     "mfnet_layernorm_bwd": [P, I, I64, P, I, I64, P, P, P, P, P, P, I64, P, P, I64, I64, P],
     "mfnet_gemm_bf16": [P, I64, P, I64, I64, I64, I64, P, P, I64, P, I64, I64, I, I, F, I, P, I64, P, I64,
                         P, I64, I64, P, I, I64, I, P],
+    "mfnet_gemm_bf16_tiled": [P, I64, P, I64, I64, I64, I64, P, P, I64, P, I64, I64, I, I, F, I, P, I64, P, I64,
+                              P, I64, I64, P, I, I64, I, I, P],
     "mfnet_gemm_bf16_grouped": [P, I64, P, I64, I64, I64, I64, I64, P, I64, I64, I, I, P, I64, P, I64, P, I64, P, I, I64, P],
     "mfnet_skinny_nt": [P, I64, P, I64, I64, I64, I, P, I64, I64, I64, I, F, P],
     "mfnet_skinny_tn": [P, I64, P, I64, P, I64, I64, I, I, F, I, I64, P, I64, P],

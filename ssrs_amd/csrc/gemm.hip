@@ -20,32 +20,20 @@
 // row: the epilogue loads bias/V/residual and stores C with 16-byte accesses. Workgroup ids are
 // remapped so each XCD walks a contiguous run of tiles (shared A panel in its private L2).
 #include "common.h"
+#include "gemm_params.h"
 
 #define BM 128
 #define BN 128
 #define BK 64
-#define GEMM_MAX_R 16
 
-struct GemmParams {
-  const bf16_t* A; int64_t lda;
-  const bf16_t* W; int64_t ldw;
-  int M, N, K;
-  const float* bias;
-  const float* U; int64_t ldu;
-  const float* V; int64_t v_group_stride; int64_t rows_per_group; int n_groups; int R; float lr_scale;
-  int act;                              // 0 none, 1 gelu, 2 *gelu'(aux), 3 relu6, 4 *relu6'(aux = relu6 output), 5 relu6 AFTER the residual add
-  const bf16_t* aux; int64_t ldaux;
-  bf16_t* out_pre; int64_t ldpre;
-  const float* residual; int64_t ldres; int64_t res_row_mod;
-  void* out; int out_dtype; int64_t ldc;
-  int tiles_m, tiles_n;
-  int k_splits;                         // > 1: blockIdx.y owns a K range and stores its fp32 partial into slice blockIdx.y of out
-  int64_t w_group_stride, bias_group_stride;   // != 0: W / bias of row group g start g * stride elements further (per-modality layers)
-};
 
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
+#ifdef GEMM_STAMPS
+unsigned long long* g_stamps = nullptr;
+int g_stagger = 0;
+extern "C" void mfnet_diag_set_stamps(unsigned long long* p) { g_stamps = p; }
+extern "C" void mfnet_diag_set_stagger(int ticks) { g_stagger = ticks; }
+#endif
 __device__ __forceinline__ int swz_x(int row) { return row & 7; }
 __device__ __forceinline__ int swz_w(int row) { return (((row >> 4) & 3) << 1) | ((row >> 1) & 1); }
 
@@ -59,6 +47,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+  MF_STAMP(0);
+#ifdef GEMM_STAMPS
+  if (p.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {        // experiment: second resident workgroup of each CU starts late
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < p.stagger) __builtin_amdgcn_s_sleep(32);
+  }
+  if (p.stamps && threadIdx.x == 0) {
+    p.stamps[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);    // HW_ID
+    p.stamps[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);   // XCC_ID
+  }
+#endif
 
   // XCD-aware bijective remap of the workgroup id (8 XCDs, round-robin dispatch)
   const int nwg = p.tiles_m * p.tiles_n;
@@ -182,6 +181,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
   for (int t = t_begin; t < t_end; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef GEMM_STAMPS
+    if (t == t_begin) MF_STAMP(1);
+#endif
     if (t + 1 < t_end) stage(t + 1, (t + 1 - t_begin) & 1);
     const unsigned char* base = lds + ((t - t_begin) & 1) * ((BM + BN) * BK * 2);
     const int nks = (half_tail && t == nt - 1) ? 1 : 2;
@@ -204,6 +206,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
   }
 
   // ---- epilogue
+  MF_STAMP(2);
   if (LORA) {
     // branch-free conversion: `lo` and a zero scale are lane selects
     auto conv = [&](const float4 (&raw)[2], float sc, bool lo) -> bf16x8_t {
@@ -355,6 +358,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
       }
     }
   }
+#ifdef GEMM_STAMPS
+  MF_STAMP(3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  MF_STAMP(4);
+#endif
 }
 
 static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t w_group_stride, int64_t M, int64_t N,
@@ -362,7 +370,7 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int
                      int64_t v_group_stride, int64_t rows_per_group, int n_groups, int R,
                      float lr_scale, int act, const void* aux, int64_t ldaux, void* out_pre,
                      int64_t ldpre, const float* residual, int64_t ldres, int64_t res_row_mod,
-                     void* out, int out_dtype, int64_t ldc, int k_splits, hipStream_t stream) {
+                     void* out, int out_dtype, int64_t ldc, int k_splits, hipStream_t stream, int tile = 0) {
   MF_CHECK_ARG(A && W && out, "gemm_bf16: null operand");
   MF_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm_bf16: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   MF_CHECK_ARG(K % 32 == 0, "gemm_bf16: K=%lld must be a multiple of 32", (long long)K);
@@ -400,7 +408,7 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int
                                      aux ? (const char*)aux + r0 * ldaux * 2 : nullptr, ldaux,
                                      out_pre ? (char*)out_pre + r0 * ldpre * 2 : nullptr, ldpre,
                                      residual ? residual + r0 * ldres : nullptr, ldres, 0,
-                                     (char*)out + r0 * ldc * osz, out_dtype, ldc, 1, stream);
+                                     (char*)out + r0 * ldc * osz, out_dtype, ldc, 1, stream, tile);
       if (rc) return rc;
     }
     return MFNET_OK;
@@ -418,6 +426,14 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int
   MF_CHECK_ARG(nwg < (1ll << 31), "gemm_bf16: too many tiles");
   p.k_splits = k_splits;
   p.w_group_stride = w_group_stride; p.bias_group_stride = bias_group_stride;
+#ifdef GEMM_STAMPS
+  p.stamps = g_stamps; p.stagger = g_stagger;
+#endif
+  // the encoder's big token matrices go to the 256-row kernel (gemm_big.hip) when their shape is one of its
+  const int big = gemm_big_launch(p, act, U != nullptr, tile, stream);
+  if (big == 1) { MF_LAUNCH_CHECK("gemm_bf16 (256-row tiles)"); return MFNET_OK; }
+  MF_CHECK_ARG(tile <= 0, "gemm_bf16: tile=%d asked for, but M=%lld N=%lld K=%lld is not a shape of the 256-row kernel (M %% 256, K %% 64, N %% (32*tile))",
+               tile, (long long)M, (long long)N, (long long)K);
   const dim3 grid((unsigned)nwg, (unsigned)k_splits);
 #define MF_GEMM_LAUNCH(A_, L_) hipLaunchKernelGGL((gemm_bf16_kernel<A_, L_>), grid, dim3(256), 0, stream, p)
 #define MF_GEMM_CASE(A_) case A_: if (U) MF_GEMM_LAUNCH(A_, true); else MF_GEMM_LAUNCH(A_, false); break;
@@ -436,6 +452,18 @@ extern "C" int mfnet_gemm_bf16(const void* A, int64_t lda, const void* W, int64_
                                void* out, int out_dtype, int64_t ldc, int k_splits, hipStream_t stream) {
   return gemm_impl(A, lda, W, ldw, 0, M, N, K, bias, 0, U, ldu, V, v_group_stride, rows_per_group, n_groups, R, lr_scale, act, aux, ldaux,
                    out_pre, ldpre, residual, ldres, res_row_mod, out, out_dtype, ldc, k_splits, stream);
+}
+
+// mfnet_gemm_bf16 with the tile shape named by the caller (benchmarks, tests): tile 0 = the library's choice, -1 = the 128x128
+// kernel, 3 / 4 / 6 / 8 / 9 = 256 x (32*tile) tiles.
+extern "C" int mfnet_gemm_bf16_tiled(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int64_t N,
+                                     int64_t K, const float* bias, const float* U, int64_t ldu, const float* V,
+                                     int64_t v_group_stride, int64_t rows_per_group, int n_groups, int R,
+                                     float lr_scale, int act, const void* aux, int64_t ldaux, void* out_pre,
+                                     int64_t ldpre, const float* residual, int64_t ldres, int64_t res_row_mod,
+                                     void* out, int out_dtype, int64_t ldc, int k_splits, int tile, hipStream_t stream) {
+  return gemm_impl(A, lda, W, ldw, 0, M, N, K, bias, 0, U, ldu, V, v_group_stride, rows_per_group, n_groups, R, lr_scale, act, aux, ldaux,
+                   out_pre, ldpre, residual, ldres, res_row_mod, out, out_dtype, ldc, k_splits, stream, tile);
 }
 
 // Per-modality dense layers in one launch: rows [g*rows_per_group, (g+1)*rows_per_group) (cyclically over n_groups) multiply

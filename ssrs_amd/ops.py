@@ -128,7 +128,7 @@ def zeros(shape, device):
 
 
 def gemm(a, w, *, bias=None, U=None, V=None, rows_per_group=0, n_groups=1, lr_scale=1.0, act=0, aux=None,
-         want_pre=False, residual=None, res_row_mod=0, out=None, out_dtype=torch.bfloat16, k_splits=1):
+         want_pre=False, residual=None, res_row_mod=0, out=None, out_dtype=torch.bfloat16, k_splits=1, tile=0):
     """out = a @ w^T (+bias +U V_g^T) -> act -> (+residual). a [M,K] bf16, w [N,K] bf16.
     V: [G,N,R] fp32. act: 0 none, 1 gelu (want_pre also returns the pre-activation), 2 multiply by
     gelu'(aux). Returns out or (out, pre)."""
@@ -154,11 +154,15 @@ def gemm(a, w, *, bias=None, U=None, V=None, rows_per_group=0, n_groups=1, lr_sc
     if GEMM_TRACE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record(torch.cuda.current_stream(a.device))
-    call("mfnet_gemm_bf16", a2.data_ptr(), lda, w.data_ptr(), w.stride(0), M, N, K, _p(bias),
-         _p(U), R if U is not None else 0, _p(V), vgs, rows_per_group, n_groups, R, float(lr_scale), act,
-         _p(aux), aux.stride(-2) if aux is not None else 0, _p(pre), N if pre is not None else 0,
-         _p(residual), residual.stride(-2) if residual is not None else 0, res_row_mod,
-         out.data_ptr(), _DT[out.dtype], out.stride(-2), k_splits, _stream(a))
+    args = (a2.data_ptr(), lda, w.data_ptr(), w.stride(0), M, N, K, _p(bias),
+            _p(U), R if U is not None else 0, _p(V), vgs, rows_per_group, n_groups, R, float(lr_scale), act,
+            _p(aux), aux.stride(-2) if aux is not None else 0, _p(pre), N if pre is not None else 0,
+            _p(residual), residual.stride(-2) if residual is not None else 0, res_row_mod,
+            out.data_ptr(), _DT[out.dtype], out.stride(-2), k_splits)
+    if tile:         # the caller names the tile shape (tests / benchmarks): -1 = 128x128 kernel, 3/4/6/8/9 = 256 x 32*tile
+        call("mfnet_gemm_bf16_tiled", *args, int(tile), _stream(a))
+    else:
+        call("mfnet_gemm_bf16", *args, _stream(a))
     if GEMM_TRACE is not None:
         ev1.record(torch.cuda.current_stream(a.device))
         GEMM_TRACE.append((ev0, ev1, 2.0 * M * N * K, (M, N, K)))

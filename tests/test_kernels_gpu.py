@@ -110,6 +110,73 @@ def test_gemm_lowrank_gelu_residual(ops, R, G):
     assert rel_err(out4, a.double() @ w.double().t() + pos.double().repeat(M // 256, 1)) < 1e-5
 
 
+@pytest.mark.parametrize("tile,N", [(3, 192), (4, 256), (6, 384), (8, 512), (9, 576), (-1, 256)])
+@pytest.mark.parametrize("K", [64, 448])
+def test_gemm_tile_shapes_all_epilogues(ops, tile, N, K):
+    """Every tile shape of the 256-row kernel (tile = column fragments per wave: 256 x 32*tile tiles, lanes own runs of 16 / 8 / 4
+    columns) and the 128x128 kernel (-1) through every epilogue, against fp64: bias + two-group rank-8 update + GELU with the
+    pre-activation, x GELU'(aux), fp32 residual in place, ReLU6 (3), ReLU6 mask of aux (4), ReLU6 after the residual (5), a
+    rank-16 and a rank-4 update, broadcast residual rows; and A = I with an asymmetric W (exact)."""
+    M = 512
+    a = rnd(M, K, seed=1).to(torch.bfloat16)
+    w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+    bias = rnd(N, seed=3)
+    U, V = rnd(M, 8, seed=4), rnd(2, N, 8, seed=5)
+    res = rnd(M, N, seed=6)
+    aux = rnd(M, N, seed=7, scale=3.0).to(torch.bfloat16)
+    ad, wd = a.double(), w.double()
+    base = ad @ wd.t()
+    low = torch.cat([U[g * 256:(g + 1) * 256].double() @ V[g].double().t() for g in range(2)]) * 0.25
+    lora = dict(U=U, V=V, rows_per_group=256, n_groups=2, lr_scale=0.25)
+    out, pre = ops.gemm(a, w, bias=bias, act=1, want_pre=True, tile=tile, **lora)
+    ref = base + bias.double() + low
+    assert rel_err(pre.float(), ref) < 5e-3 and rel_err(out.float(), F.gelu(ref)) < 5e-3
+    x = aux.double().requires_grad_()
+    F.gelu(x).sum().backward()
+    out = ops.gemm(a, w, act=2, aux=aux, out_dtype=torch.float32, tile=tile, **lora)
+    assert rel_err(out, (base + low) * x.grad) < 2e-5
+    out = res.clone()
+    ops.gemm(a, w, bias=bias, residual=out, out=out, tile=tile, **lora)
+    assert rel_err(out, ref + res.double()) < 1e-5
+    out = ops.gemm(a, w, bias=bias, act=3, tile=tile)
+    assert rel_err(out.float(), (base + bias.double()).clamp(0, 6)) < 5e-3
+    mask = ((aux.double() > 0) & (aux.double() < 6)).double()
+    out = ops.gemm(a, w, act=4, aux=aux, out_dtype=torch.float32, tile=tile)
+    assert rel_err(out, base * mask) < 1e-5
+    out = ops.gemm(a, w, act=5, residual=res, out_dtype=torch.float32, tile=tile)
+    assert rel_err(out, (base + res.double()).clamp(0, 6)) < 1e-5
+    U16, V16 = rnd(M, 16, seed=8), rnd(N, 16, seed=9)
+    out = ops.gemm(a, w, U=U16, V=V16, lr_scale=0.5, out_dtype=torch.float32, tile=tile)
+    assert rel_err(out, base + 0.5 * U16.double() @ V16.double().t()) < 2e-5
+    U4, V4 = rnd(M, 4, seed=10), rnd(N, 4, seed=11)
+    out = ops.gemm(a, w, U=U4, V=V4, out_dtype=torch.float32, tile=tile)
+    assert rel_err(out, base + U4.double() @ V4.double().t()) < 2e-5
+    pos = rnd(256, N, seed=12)
+    out = ops.gemm(a, w, residual=pos, res_row_mod=256, out_dtype=torch.float32, tile=tile)
+    assert rel_err(out, base + pos.double().repeat(2, 1)) < 1e-5
+    Ki = (N + 63) // 64 * 64
+    eye = torch.zeros((Ki + 255) // 256 * 256, Ki, device="cuda")
+    eye[:N, :N] = torch.eye(N, device="cuda")
+    wi = torch.zeros(N, Ki, device="cuda")
+    wi[:, :N] = (torch.arange(N * N, device="cuda").reshape(N, N) % 251).float()
+    out = ops.gemm(eye.to(torch.bfloat16), wi.to(torch.bfloat16), out_dtype=torch.float32, tile=tile)
+    assert torch.equal(out[:N], wi[:, :N].t().contiguous())
+
+
+def test_gemm_encoder_shapes_take_the_big_tiles_and_match(ops):
+    """The shapes of the ViT-B step at 16 tiles (M = 8192): the library's own choice (256-row tiles) against the 128x128 kernel."""
+    for N, K in ((768, 768), (2304, 768), (3072, 768), (768, 3072), (768, 2304)):
+        a = rnd(8192, K, seed=1).to(torch.bfloat16)
+        w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+        bias = rnd(N, seed=3)
+        got = ops.gemm(a, w, bias=bias, out_dtype=torch.float32)
+        ref = ops.gemm(a, w, bias=bias, out_dtype=torch.float32, tile=-1)
+        assert rel_err(got, ref) < 1e-5, (N, K)
+    from ssrs_amd._lib import MfnetError
+    with pytest.raises(MfnetError):
+        ops.gemm(rnd(100, 64).to(torch.bfloat16), rnd(96, 64).to(torch.bfloat16), tile=3)          # M % 256 != 0
+
+
 def test_gemm_rejects_bad_shapes(ops):
     from ssrs_amd._lib import MfnetError
     a = torch.zeros(64, 100, device="cuda", dtype=torch.bfloat16)
