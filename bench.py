@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0               # HBM3E spec (6.3 TB/s is what a float4 copy reaches), same guide
 TRAIN_GF_PER_TILE = {"sam_lora": 191.0, "sam_adpt": 211.0}     # SURVEY.md 8(d), tools/flops.py
 
 
@@ -101,8 +102,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with `python -m torch.distributed.run --nproc-per-node N ...`")
+        if world == 1 and a.gpus > 1 and "RANK" not in os.environ:
+            # started plainly with --gpus N: become the launcher. No GPU call has been made in this process, so N fresh children
+            # (one rank per GPU, RCCL over xGMI) are started through torch.distributed.run and this process only relays their
+            # output and exit code.
+            import socket
+            import subprocess
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            sys.exit(subprocess.run(cmd).returncode)
         a.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a ROCm GPU: the MFNet hot path has no CPU fallback")
@@ -168,16 +179,17 @@ def main():
         dt = t.item()
     metrics = TrainEngine.read_metrics(acc)
 
-    roofline = None
+    roofline = roofline_hbm = None
     if not a.no_roofline:
         # second pass over the same steps, eagerly, with an event pair around every GEMM launch. Every rank takes
         # it (the steps contain the gradient all-reduce, a collective); rank 0's launches are the ones reported.
         eng.use_graph = False
-        ops.GEMM_TRACE = []
+        ops.GEMM_TRACE, ops.LN_BWD_TRACE = [], []
         for _ in range(a.steps):
             eng.step(rgb, dsm, tgt)
         torch.cuda.synchronize()
         tr, ops.GEMM_TRACE = ops.GEMM_TRACE, None
+        tr_ln, ops.LN_BWD_TRACE = ops.LN_BWD_TRACE, None
     if rank == 0 and not a.no_roofline:
         # an event pair with nothing between its two records still reads a few microseconds apart; that offset
         # (median of 64 empty pairs) is taken off every launch so the figure agrees with rocprofv3's kernel durations
@@ -199,11 +211,24 @@ def main():
         if pmc and a.mod == "sam_lora" and a.batch == 16 and a.encoder == "vit_b" and a.tile == 256:
             with open(pmc[-1]) as f:
                 traffic = round(json.load(f)["traffic_bytes_per_launch"])
-        roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(achieved, 2),
+        roofline = {"bound": "mfma", "kernel": "gemm_big_kernel + gemm_bf16_kernel", "achieved": round(achieved, 2),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": traffic, "launches_per_step": len(tr) // a.steps,
                     "avg_launch_us": round(1e3 * ms / len(tr), 2), "gflop_per_launch": round(fl / len(tr) / 1e9, 3),
                     "gemm_ms_per_step": round(ms / a.steps, 3), "event_pair_offset_us": round(1e3 * ev_over, 2)}
+        # the largest HBM-bound kernel of the step (LayerNorm backward of the residual stream: one streaming pass)
+        ms_ln = sum(max(t[0].elapsed_time(t[1]) - ev_over, 0.0) for t in tr_ln)
+        by_ln = sum(t[2] for t in tr_ln)
+        if tr_ln and ms_ln > 0:
+            gbs = by_ln / (ms_ln * 1e-3) / 1e9
+            pmc_ln = sorted(glob.glob(os.path.join(ROOT, "profiles", "*ln_bwd_pmc.json")))
+            traffic_ln = None
+            if pmc_ln and a.mod == "sam_lora" and a.batch == 16 and a.encoder == "vit_b" and a.tile == 256:
+                with open(pmc_ln[-1]) as f:
+                    traffic_ln = round(json.load(f)["traffic_bytes_per_launch"])
+            roofline_hbm = {"bound": "hbm", "kernel": "ln_bwd_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic_ln, "launches_per_step": len(tr_ln) // a.steps,
+                            "avg_launch_us": round(1e3 * ms_ln / len(tr_ln), 2), "mbytes_per_launch": round(by_ln / len(tr_ln) / 1e6, 2)}
         if os.environ.get("MFNET_GEMM_SHAPES"):          # developer aid: per-shape GEMM time on stderr
             agg = {}
             for e0, e1, f, shp in tr:
@@ -229,6 +254,8 @@ def main():
                                             if a.encoder == "vit_b" and a.tile == 256 else None)}
         if roofline is not None:
             out["roofline"] = roofline
+        if roofline_hbm is not None:
+            out["roofline_hbm"] = roofline_hbm
         if rehearsal:
             out["rehearsal"] = rehearsal + ": control-flow check only, not a measurement"
         if world == 1 and not a.no_cpu:

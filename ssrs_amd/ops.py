@@ -18,6 +18,8 @@ _DT = {torch.float32: F32, torch.bfloat16: BF16}
 # bench.py sets this to a list to time every GEMM launch with a pair of events recorded on the stream
 # the kernel is launched on: entries are (start_event, end_event, algorithmic_flops).
 GEMM_TRACE = None
+# likewise for the dominant HBM-bound kernel (ln_bwd_kernel): entries are (start_event, end_event, algorithmic_bytes)
+LN_BWD_TRACE = None
 
 
 def _stream(t: torch.Tensor):
@@ -71,9 +73,17 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, want_f32=True, want_bf16=
     # them with float atomics from every wave)
     split_w = (dgamma is not None and lddy == C and ldx == C and C % 4 == 0 and C <= 1024
                and dy2.is_contiguous() and x2.is_contiguous())
+    if LN_BWD_TRACE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(x.device))
     call("mfnet_layernorm_bwd", dy2.data_ptr(), _DT[dy.dtype], lddy, x2.data_ptr(), _DT[x.dtype], ldx,
          mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), _p(dres), _p(dx), _p(dxb), C,
          None if split_w else _p(dgamma), None if split_w else _p(dbeta), rows, C, _stream(x))
+    if LN_BWD_TRACE is not None:
+        ev1.record(torch.cuda.current_stream(x.device))
+        # every operand is streamed once: dy, x (+ the residual gradient) in, dx (fp32 and / or bf16) out, the row statistics
+        per_el = dy.element_size() + x.element_size() + (4 if dres is not None else 0) + (4 if want_f32 else 0) + (2 if want_bf16 else 0)
+        LN_BWD_TRACE.append((ev0, ev1, rows * C * per_el + rows * 8, (rows, C)))
     if split_w:
         ws, tk = _colreduce_ws(1, rows, C, x.device)
         call("mfnet_layernorm_bwd_weights", dy2.data_ptr(), _DT[dy.dtype], x2.data_ptr(), _DT[x.dtype], mean.data_ptr(), rstd.data_ptr(),

@@ -134,6 +134,7 @@ class TrainEngine:
         self._pending = [0] * len(self.bucket_bounds)
         self._works = []
         self._launched = [False] * len(self.bucket_bounds)
+        self._seen = set()
         self._bucket_size = [self.bucket_of.count(b) for b in range(len(self.bucket_bounds))]
         self._hooks = []
         # Gradients are added into flat_g by the modules' backward passes themselves (bank.deliver: one gather
@@ -162,6 +163,11 @@ class TrainEngine:
     # ---- data-parallel gradient exchange
     def _make_hook(self, b):
         def hook(_p):
+            # a tensor is counted ONCE per step: a gradient handed over by bank.deliver notifies from there (its gather is
+            # enqueued at that point), and autograd's accumulate hook still fires afterwards for the same tensor
+            if id(_p) in self._seen:
+                return
+            self._seen.add(id(_p))
             self._pending[b] += 1
             if self._pending[b] == self._bucket_size[b] and self.overlap:
                 self._launch(b)
@@ -202,6 +208,7 @@ class TrainEngine:
         self._works.clear()
         self._pending = [0] * len(self.bucket_bounds)
         self._launched = [False] * len(self.bucket_bounds)
+        self._seen.clear()
 
     # ---- one step
     def zero_grad(self):
