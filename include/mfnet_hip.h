@@ -112,8 +112,23 @@ int64_t mfnet_skinny_tn_workspace_floats(int64_t M, int64_t C, int R, int n_grou
  * U [M,2r]: RGB rows [wx*ax, (1-wx)*ay], DSM rows [(1-wy)*ax, wy*ay]; backward returns da and ADDS
  * (d lora_wx, d lora_wy) into dw[2]. wx/wy: device pointers to the trainable scalars. */
 int mfnet_lora_mix_fwd(const float* a, const float* wx, const float* wy, float* U, int64_t M, int r, hipStream_t stream);
-int mfnet_lora_mix_bwd(const float* P, const float* a, const float* wx, const float* wy, float* da, float* dw,
-                       int64_t M, int r, hipStream_t stream);
+/* P = the sum of `nparts` partial matrices [M,2r], part_stride floats apart (nparts = 1: P itself; the column strips of
+ * mfnet_lora_side otherwise). */
+int mfnet_lora_mix_bwd(const float* P, int nparts, int64_t part_stride, const float* a, const float* wx, const float* wy, float* da,
+                       float* dw, int64_t M, int r, hipStream_t stream);
+
+/* ---- both rank-r products of a LoRA layer's backward in ONE pass over the output gradient Y [n_groups*Mg, C] bf16
+ * (loralib/layers.py:149-165, 244-268 differentiated; group g = rows [g*Mg, (g+1)*Mg) = one modality):
+ *   p_part[strip][m][j]     = sum_{c in strip} Y[m,c] * Vt[g][j][c]   (strips of 256 columns; [ceil(C/256)][n_groups*Mg][8] fp32,
+ *                             j >= RP are zero) - its sum over the strips is Y . B, the gradient w.r.t. the down-projection x A^T;
+ *   dv_part[g][s][c][j]     = sum_{m in split s} Y[m,c] * U[m][j]     ([n_groups][mfnet_lora_side_splits(Mg, C)][C][R] fp32) - its
+ *                             sum over the splits is dB = Y^T . u.
+ * U (fp32 [n_groups*Mg, R], R = 4 or 8, row stride ldu) or Vt (fp32 [RP <= 8][C] per group, vt_group_stride floats apart) may be
+ * NULL: then only the other product is computed (Vt == NULL, U = d(xA^T): dA^T = x^T . da of the same layer). C % 64 == 0. */
+int64_t mfnet_lora_side_splits(int64_t Mg, int64_t C);
+int mfnet_lora_side(const void* Y, int64_t ldy, int64_t Mg, int64_t C, int n_groups, const float* U, int64_t ldu, int R,
+                    float* dv_part, const float* Vt, int64_t ldvt, int64_t vt_group_stride, int RP, float* p_part,
+                    hipStream_t stream);
 
 /* ---- fused attention of the SAM blocks (lora_block.py:169-196 / adapter_fusionblock.py:176-198 with
  * add_decomposed_rel_pos :281-317, window_partition / window_unpartition :199-245).

@@ -43,7 +43,8 @@ _SIGS = {
     "mfnet_im2col3x3": [P, P, I64, I64, I64, I64, P],
     "mfnet_col2im3x3": [P, P, I64, I64, I64, I64, P],
     "mfnet_lora_mix_fwd": [P, P, P, P, I64, I, P],
-    "mfnet_lora_mix_bwd": [P, P, P, P, P, P, I64, I, P],
+    "mfnet_lora_mix_bwd": [P, I, I64, P, P, P, P, P, I64, I, P],
+    "mfnet_lora_side": [P, I64, I64, I64, I, P, I64, I, P, P, I64, I64, I, P, P],
     "mfnet_attn_fwd": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, F, P],
     "mfnet_attn_bwd": [P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, F, P, I64, P],
     "mfnet_ce_loss_fwd": [P, P, P, P, P, I64, I64, I64, I64, P],
@@ -125,6 +126,8 @@ def lib():
         L.mfnet_skinny_tn_workspace_floats.argtypes = [c_int64, c_int64, c_int, c_int]
         L.mfnet_colreduce_workspace_floats.restype = c_int64
         L.mfnet_colreduce_workspace_floats.argtypes = [c_int64, c_int64, c_int64]
+        L.mfnet_lora_side_splits.restype = c_int64
+        L.mfnet_lora_side_splits.argtypes = [c_int64, c_int64]
         L.mfnet_gemm_tn_splits.restype = c_int64
         L.mfnet_gemm_tn_splits.argtypes = [c_int64, c_int64, c_int64]
         L.mfnet_attn_bwd_workspace_floats.restype = c_int64
@@ -141,7 +144,7 @@ def lib():
 
 def exported_symbols():
     return ["mfnet_version", "mfnet_last_error", "mfnet_skinny_tn_workspace_floats", "mfnet_gemm_tn_splits", "mfnet_colreduce_workspace_floats",
-            "mfnet_attn_bwd_workspace_floats"] + list(_SIGS)
+            "mfnet_attn_bwd_workspace_floats", "mfnet_lora_side_splits"] + list(_SIGS)
 
 
 def call(name: str, *args):

@@ -153,9 +153,10 @@ __global__ __launch_bounds__(256) void lora_mix_fwd_kernel(const float* __restri
 }
 // P [M, 2r] = g @ [Bx|By].  da [M, r]: x rows <- wx*Px[:, :r] + (1-wy)*Py[:, :r] ; y rows <- (1-wx)*Px[:, r:] + wy*Py[:, r:]
 // dw[0] += sum Px[:, :r]*ax - Px[:, r:]*ay ; dw[1] += sum Py[:, r:]*ay - Py[:, :r]*ax
-__global__ __launch_bounds__(256) void lora_mix_bwd_kernel(const float* __restrict__ P, const float* __restrict__ a,
+__global__ __launch_bounds__(256) void lora_mix_bwd_kernel(const float* __restrict__ P, int nparts, int64_t part_stride, const float* __restrict__ a,
                                                            const float* __restrict__ wx, const float* __restrict__ wy,
                                                            float* __restrict__ da, float* __restrict__ dw, int64_t Mh, int r) {
+  // P is the sum of `nparts` partial matrices part_stride floats apart (the column strips of mfnet_lora_side)
   const float fx = wx[0], fy = wy[0];
   const int64_t total = Mh * r;
   float sx = 0.f, sy = 0.f;
@@ -163,8 +164,12 @@ __global__ __launch_bounds__(256) void lora_mix_bwd_kernel(const float* __restri
     const int64_t t = i / r;
     const int j = (int)(i % r);
     const float ax = a[t * r + j], ay = a[(Mh + t) * r + j];
-    const float pxx = P[t * 2 * r + j], pxy = P[t * 2 * r + r + j];
-    const float pyx = P[(Mh + t) * 2 * r + j], pyy = P[(Mh + t) * 2 * r + r + j];
+    float pxx = 0.f, pxy = 0.f, pyx = 0.f, pyy = 0.f;
+    for (int s = 0; s < nparts; ++s) {
+      const float* Ps = P + (int64_t)s * part_stride;
+      pxx += Ps[t * 2 * r + j]; pxy += Ps[t * 2 * r + r + j];
+      pyx += Ps[(Mh + t) * 2 * r + j]; pyy += Ps[(Mh + t) * 2 * r + r + j];
+    }
     da[t * r + j] = fx * pxx + (1.f - fy) * pyx;
     da[(Mh + t) * r + j] = (1.f - fx) * pxy + fy * pyy;
     sx += pxx * ax - pxy * ay;
@@ -186,13 +191,14 @@ extern "C" int mfnet_lora_mix_fwd(const float* a, const float* wx, const float* 
   return MFNET_OK;
 }
 // dw (2 floats: d lora_wx, d lora_wy) is accumulated into; zero it first.
-extern "C" int mfnet_lora_mix_bwd(const float* P, const float* a, const float* wx, const float* wy, float* da, float* dw,
-                                  int64_t M, int r, hipStream_t stream) {
-  MF_CHECK_ARG(P && a && wx && wy && da && dw && r > 0 && M % 2 == 0, "lora_mix_bwd: bad args");
+extern "C" int mfnet_lora_mix_bwd(const float* P, int nparts, int64_t part_stride, const float* a, const float* wx, const float* wy, float* da,
+                                  float* dw, int64_t M, int r, hipStream_t stream) {
+  MF_CHECK_ARG(P && a && wx && wy && da && dw && r > 0 && M % 2 == 0 && nparts >= 1 && (nparts == 1 || part_stride >= M * 2 * r),
+               "lora_mix_bwd: bad args");
   if (M == 0) return MFNET_OK;
   unsigned g = grid_for(M / 2 * r);
   if (g > 128) g = 128;
-  hipLaunchKernelGGL(lora_mix_bwd_kernel, dim3(g), dim3(256), 0, stream, P, a, wx, wy, da, dw, M / 2, r);
+  hipLaunchKernelGGL(lora_mix_bwd_kernel, dim3(g), dim3(256), 0, stream, P, nparts, part_stride, a, wx, wy, da, dw, M / 2, r);
   MF_LAUNCH_CHECK("lora_mix_bwd");
   return MFNET_OK;
 }

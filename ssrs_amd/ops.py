@@ -350,13 +350,58 @@ def lora_mix_fwd(a, wx, wy):
 
 
 def lora_mix_bwd(P, a, wx, wy):
+    """P: [M, 2r] or a stack of partial sums [nparts, M, 2r] (the column strips of lora_side) -> (da [M, r], dw [2])."""
     _chk(P, a, wx, wy)
     M, r = a.shape
+    assert P.is_contiguous() and P.shape[-2:] == (M, 2 * r)
+    nparts = P.shape[0] if P.dim() == 3 else 1
     da = torch.empty_like(a)
     dw = zeros(2, a.device)
-    call("mfnet_lora_mix_bwd", P.data_ptr(), a.data_ptr(), wx.data_ptr(), wy.data_ptr(), da.data_ptr(),
+    call("mfnet_lora_mix_bwd", P.data_ptr(), nparts, M * 2 * r, a.data_ptr(), wx.data_ptr(), wy.data_ptr(), da.data_ptr(),
          dw.data_ptr(), M, r, _stream(a))
     return da, dw
+
+
+def lora_side(y, U=None, Vt=None, n_groups=1, scale=1.0):
+    """One pass over y [M, C] bf16 for both rank-r products of a LoRA backward:
+    dV = SplitSum of [G, C, R] partial tiles of y^T U (U fp32 [M, R], R = 4 or 8; rows of group g only), and
+    P_parts [strips, M, 8] fp32 whose sum over dim 0 is y . Vt[g]^T (Vt fp32 [RP, C] or [G, RP, C], RP <= 8; columns >= RP are 0).
+    Either product may be left out (None)."""
+    _chk(y, U, Vt)
+    y2, M, C, ldy = _rows2d(y)
+    assert y.dtype == torch.bfloat16 and M % n_groups == 0
+    Mg = M // n_groups
+    dv = pp = None
+    R = 8
+    if U is not None:
+        R = U.shape[1]
+        assert U.dtype == torch.float32 and U.stride(1) == 1 and U.shape[0] == M
+        splits = int(_lib.lib().mfnet_lora_side_splits(Mg, C))
+        dv = torch.empty((n_groups, splits, C, R), dtype=torch.float32, device=y.device)
+    RP, ldvt, vgs = 0, 0, 0
+    if Vt is not None:
+        assert Vt.dtype == torch.float32 and Vt.is_contiguous() and Vt.shape[-1] == C
+        RP, ldvt = Vt.shape[-2], C
+        vgs = Vt.stride(0) if Vt.dim() == 3 else 0
+        assert Vt.dim() == 2 or Vt.shape[0] == n_groups
+        pp = torch.empty(((C + 255) // 256, M, 8), dtype=torch.float32, device=y.device)
+    call("mfnet_lora_side", y2.data_ptr(), ldy, Mg, C, n_groups, _p(U), U.stride(0) if U is not None else 0, R, _p(dv),
+         _p(Vt), ldvt, vgs, RP, _p(pp), _stream(y))
+    if dv is not None:
+        dv = SplitSum(dv.transpose(0, 1), scale)               # [splits, G, C, R], summed (x scale) by the gradient delivery
+        if n_groups == 1:
+            dv = dv[0]
+    return dv, pp
+
+
+def reduce_parts(parts, scale=1.0):
+    """scale * sum over dim 0 of a contiguous fp32 stack (e.g. the P partials of lora_side)."""
+    _chk(parts)
+    assert parts.is_contiguous() and parts.dtype == torch.float32
+    out = torch.empty(parts.shape[1:], dtype=torch.float32, device=parts.device)
+    assert out.numel() % 4 == 0
+    call("mfnet_reduce_splits", parts.data_ptr(), out.data_ptr(), out.numel(), parts.shape[0], float(scale), 0, _stream(parts))
+    return out
 
 
 # ------------------------------------------------------------------------------------------ attention

@@ -184,9 +184,17 @@ class _LoraAttnBranch(torch.autograd.Function):
         dO = ops.gemm(d_bf, wT_bf16(attn.proj.weight))
         dqkv = ops.attn_bwd(qkv, attn.qkv.bias, tbl, tblT, o, dO, lse, 2 * B, Sh, Sw, heads, ws, Lh, Lw, hd ** -0.5)
         s = 1.0 / r
-        da = ops.skinny_nt(dqkv, _qkv_lora_V(Bx, By, D, r, transposed=True), scale=s, rows_per_group=half).contiguous()
-        dVx, dVy = _tn_groups(dqkv, a, half, False, s)
-        dAx, dAy = _tn_groups(ln, da, half, True)
+        if 2 * r == 8:
+            # one pass over dqkv for d(xA^T) = dqkv . B (per modality) and dB = dqkv^T . a; one over ln for dA^T = ln^T . da
+            dV, pp = ops.lora_side(dqkv, U=a, Vt=_qkv_lora_V(Bx, By, D, r, transposed=True), n_groups=2, scale=s)
+            da = ops.reduce_parts(pp, s)
+            dVx, dVy = dV[0], dV[1]
+            dA = ops.lora_side(ln, U=da, n_groups=2)[0]
+            dAx, dAy = dA[0].t(), dA[1].t()
+        else:
+            da = ops.skinny_nt(dqkv, _qkv_lora_V(Bx, By, D, r, transposed=True), scale=s, rows_per_group=half).contiguous()
+            dVx, dVy = _tn_groups(dqkv, a, half, False, s)
+            dAx, dAy = _tn_groups(ln, da, half, True)
         dln = ops.gemm(dqkv, wT_bf16(attn.qkv.weight), U=da, V=_stack2("A", Ax, Ay, transpose=True), rows_per_group=half, n_groups=2)
         dh, dh_bf = ops.layernorm_bwd(dln, h2, mean, rstd, blk.norm1.weight, dres=d2, want_bf16=True)
         ops.remember_bf16_twin(dh, dh_bf)
@@ -217,10 +225,16 @@ def _mix_linear_bwd(d_bf, x_bf, lin, saved, half, gelu_aux=None):
     input was GELU(pre) (then dx is the grad w.r.t. pre)."""
     a, U = saved
     r = a.shape[1]
-    P = ops.skinny_nt(d_bf, _mix_V(lin, transposed=True))
-    da, dw = ops.lora_mix_bwd(P, a, lin.lora_wx, lin.lora_wy)
-    dV = ops.skinny_tn(d_bf, U, False, lazy=True)
-    dAx, dAy = _tn_groups(x_bf, da, half, True)
+    if 2 * r == 8:
+        dV, pp = ops.lora_side(d_bf, U=U, Vt=_mix_V(lin, transposed=True))      # d_bf is read once for P = d . [Bx|By] and dB
+        da, dw = ops.lora_mix_bwd(pp, a, lin.lora_wx, lin.lora_wy)
+        dA = ops.lora_side(x_bf, U=da, n_groups=2)[0]
+        dAx, dAy = dA[0].t(), dA[1].t()
+    else:
+        P = ops.skinny_nt(d_bf, _mix_V(lin, transposed=True))
+        da, dw = ops.lora_mix_bwd(P, a, lin.lora_wx, lin.lora_wy)
+        dV = ops.skinny_tn(d_bf, U, False, lazy=True)
+        dAx, dAy = _tn_groups(x_bf, da, half, True)
     dx = ops.gemm(d_bf, wT_bf16(lin.weight), U=da, V=_stack2("A", lin.lora_Ax, lin.lora_Ay, transpose=True),
                   rows_per_group=half, n_groups=2, act=2 if gelu_aux is not None else 0, aux=gelu_aux)
     return dx, (dAx, dAy, dV[:, :r], dV[:, r:], dw[0:1], dw[1:2])

@@ -214,6 +214,45 @@ def test_skinny(ops, M, K, R):
                 assert rel_err(o2[g], rg.t() if tr else rg) < 1e-4
 
 
+@pytest.mark.parametrize("M,C,G,R,RP", [(8192, 768, 1, 8, 8), (8192, 2304, 2, 8, 8), (4096, 3072, 2, 4, 0), (1024, 1280, 2, 8, 8), (200, 64, 1, 8, 4),
+                                        (96, 320, 2, 4, 8), (8192, 3072, 1, 0, 8)])
+def test_lora_side_fused_products(ops, M, C, G, R, RP):
+    """mfnet_lora_side: both rank-r products of a LoRA backward from one pass over the gradient matrix - the row products
+    P = y . Vt[g]^T as partial sums over 256-column strips, the column products dV = y^T . u as partial tiles over row splits
+    (summed by the gradient delivery) - per modality group, ragged row counts and a last strip narrower than 256 included."""
+    y = rnd(M, C, seed=1).to(torch.bfloat16)
+    U = rnd(M, R, seed=2) if R else None
+    Vt = (rnd(G, RP, C, seed=3) if G > 1 else rnd(RP, C, seed=3)) if RP else None
+    dv, pp = ops.lora_side(y, U=U, Vt=Vt, n_groups=G, scale=0.5)
+    Mg = M // G
+    if RP:
+        assert tuple(pp.shape) == ((C + 255) // 256, M, 8)
+        P = ops.reduce_parts(pp, 2.0)
+        vt = Vt if G > 1 else Vt[None]
+        ref = torch.cat([y[g * Mg:(g + 1) * Mg].double() @ bf16r(vt[g]).double().t() for g in range(G)]) * 2.0
+        assert rel_err(P[:, :RP], ref) < 1e-5
+        assert float(P[:, RP:].abs().max()) == 0.0 if RP < 8 else True
+    else:
+        assert pp is None
+    if R:
+        got = dv.materialize()
+        got = got if G > 1 else got[None]
+        for g in range(G):
+            sl = slice(g * Mg, (g + 1) * Mg)
+            assert rel_err(got[g], 0.5 * (y[sl].double().t() @ U[sl].double())) < 1e-4, g
+        if G > 1:       # the views the block backward hands to the gradient delivery
+            assert rel_err(dv[1].t().materialize(), 0.5 * (y[Mg:].double().t() @ U[Mg:].double()).t()) < 1e-4
+    else:
+        assert dv is None
+    # partial sums feed lora_mix_bwd directly
+    if RP == 8 and G == 1 and R == 8 and M % 2 == 0:
+        a = rnd(M, 4, seed=5)
+        wx, wy = torch.tensor([0.3], device="cuda"), torch.tensor([0.9], device="cuda")
+        da1, dw1 = ops.lora_mix_bwd(pp, a, wx, wy)
+        da2, dw2 = ops.lora_mix_bwd(ops.reduce_parts(pp), a, wx, wy)
+        assert rel_err(da1, da2) < 1e-6 and rel_err(dw1, dw2) < 1e-4
+
+
 def test_lora_mix(ops):
     M, r = 2048, 4
     a = rnd(M, r, seed=1)
