@@ -157,12 +157,13 @@ int mfnet_attn_bwd(const void* qkv, const float* qkv_bias, const void* tbl, cons
 int64_t mfnet_attn_bwd_workspace_floats(int64_t G, int64_t Sh, int64_t Sw, int64_t heads, int64_t ws);
 
 /* ---- data movement of the encoder. cast: fp32 <-> bf16, n % 8 == 0. im2col_patch: rgb [B,3,H,W] fp32 and
- * dsm [B,H,W] fp32 (replicated to 3 channels, unetformer_mmsam.py:535) -> cols [2*B*(H/P)*(W/P), 3*P*P]
+ * dsm [B,H,W] fp32 (dsm_channels = 1: replicated to 3 channels, unetformer_mmsam.py:535) or [B,3,H,W] (dsm_channels = 3: a
+ * second 3-channel image, the general ImageEncoderViT.forward(x, y) of image_encoder.py:122-144) -> cols [2*B*(H/P)*(W/P), 3*P*P]
  * bf16, RGB rows first, k in conv-weight order (image_encoder.py:189-197). im2col3x3 / col2im3x3: NHWC 3x3
  * pad-1 unfold / fold for the neck conv and its dgrad (image_encoder.py:112-118). transpose_bf16:
  * x [M,N] -> y [N,Mp] zero-padded (operand prep for adapter wgrads). */
 int mfnet_cast(const void* x, int x_dtype, void* y, int y_dtype, int64_t n, hipStream_t stream);
-int mfnet_im2col_patch(const float* rgb, const float* dsm, void* cols, int64_t B, int64_t H, int64_t W, int64_t P,
+int mfnet_im2col_patch(const float* rgb, const float* dsm, int dsm_channels, void* cols, int64_t B, int64_t H, int64_t W, int64_t P,
                        hipStream_t stream);
 int mfnet_im2col3x3(const void* x, void* cols, int64_t G, int64_t H, int64_t W, int64_t C, hipStream_t stream);
 int mfnet_col2im3x3(const void* dcols, float* dx, int64_t G, int64_t H, int64_t W, int64_t C, hipStream_t stream);

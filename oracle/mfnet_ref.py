@@ -297,7 +297,7 @@ def global_local_attention(sd, p, x, st, heads: int, ws: int):
     B, C, H, W = x.shape
     local = conv_bn(sd, p + "local2.", x, st, 1) + conv_bn(sd, p + "local1.", x, st, 3)
     if W % ws:
-        x = F.pad(x, (0, ws - W % ws), mode="reflect")
+        x = F.pad(x, (0, ws - W % ws, 0, 0), mode="reflect")      # the reference's 2-tuple form; this torch wants all 4
     if H % ws:
         x = F.pad(x, (0, 0, 0, ws - H % ws), mode="reflect")
     Hp, Wp = x.shape[2:]

@@ -39,7 +39,7 @@ _SIGS = {
     "mfnet_skinny_nt": [P, I64, P, I64, I64, I64, I, P, I64, I64, I64, I, F, P],
     "mfnet_skinny_tn": [P, I64, P, I64, P, I64, I64, I, I, F, I, I64, P, I64, P],
     "mfnet_cast": [P, I, P, I, I64, P],
-    "mfnet_im2col_patch": [P, P, P, I64, I64, I64, I64, P],
+    "mfnet_im2col_patch": [P, P, I, P, I64, I64, I64, I64, P],
     "mfnet_im2col3x3": [P, P, I64, I64, I64, I64, P],
     "mfnet_col2im3x3": [P, P, I64, I64, I64, I64, P],
     "mfnet_lora_mix_fwd": [P, P, P, P, I64, I, P],

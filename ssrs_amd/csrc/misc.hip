@@ -43,8 +43,9 @@ extern "C" int mfnet_cast(const void* x, int x_dtype, void* y, int y_dtype, int6
 // rgb [B,3,H,W] fp32 and dsm [B,H,W] fp32 (replicated to 3 channels, unetformer_mmsam.py:535) ->
 // cols [2*B*T, 3*P*P] bf16, row = (modality, b, ph, pw), k = c*P*P + py*P + px  (conv weight order,
 // image_encoder.py:189-197). One thread = 8 consecutive px.
+// dsm_ch = 1: the second modality is one plane per image, replicated over the 3 input channels; 3: a real 3-channel image.
 __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restrict__ rgb, const float* __restrict__ dsm,
-                                                           bf16_t* __restrict__ cols, int B, int H, int W, int P) {
+                                                           bf16_t* __restrict__ cols, int B, int H, int W, int P, int dsm_ch) {
   const int Sh = H / P, Sw = W / P;
   const int K = 3 * P * P, K8 = K >> 3, P8 = P >> 3;
   const int64_t total = (int64_t)2 * B * Sh * Sw * K8;
@@ -55,20 +56,22 @@ __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restri
     const int pw = (int)(row % Sw), ph = (int)((row / Sw) % Sh);
     const int b = (int)((row / ((int64_t)Sw * Sh)) % B), mod = (int)(row / ((int64_t)Sw * Sh * B));
     const int y = ph * P + py, x = pw * P + px8 * 8;
-    const float* src = mod == 0 ? rgb + (((int64_t)b * 3 + c) * H + y) * W + x : dsm + ((int64_t)b * H + y) * W + x;
+    const float* src = mod == 0 ? rgb + (((int64_t)b * 3 + c) * H + y) * W + x
+                                : dsm + (((int64_t)b * dsm_ch + (dsm_ch == 3 ? c : 0)) * H + y) * W + x;
     const float4 a = *reinterpret_cast<const float4*>(src), bb = *reinterpret_cast<const float4*>(src + 4);
     u32x4_t w;
     w.x = pack_bf16x2(a.x, a.y); w.y = pack_bf16x2(a.z, a.w); w.z = pack_bf16x2(bb.x, bb.y); w.w = pack_bf16x2(bb.z, bb.w);
     *reinterpret_cast<u32x4_t*>(cols + row * K + (int64_t)k8 * 8) = w;
   }
 }
-extern "C" int mfnet_im2col_patch(const float* rgb, const float* dsm, void* cols, int64_t B, int64_t H, int64_t W,
+extern "C" int mfnet_im2col_patch(const float* rgb, const float* dsm, int dsm_channels, void* cols, int64_t B, int64_t H, int64_t W,
                                   int64_t P, hipStream_t stream) {
   MF_CHECK_ARG(rgb && dsm && cols, "im2col_patch: null pointer");
+  MF_CHECK_ARG(dsm_channels == 1 || dsm_channels == 3, "im2col_patch: the second modality has 1 or 3 channels, not %d", dsm_channels);
   MF_CHECK_ARG(P > 0 && P % 8 == 0 && H % P == 0 && W % P == 0 && W % 4 == 0, "im2col_patch: bad geometry H=%lld W=%lld P=%lld", (long long)H, (long long)W, (long long)P);
   if (B <= 0) return MFNET_OK;
   const int64_t total = 2 * B * (H / P) * (W / P) * (3 * P * P / 8);
-  hipLaunchKernelGGL(im2col_patch_kernel, dim3(grid_for(total)), dim3(256), 0, stream, rgb, dsm, (bf16_t*)cols, (int)B, (int)H, (int)W, (int)P);
+  hipLaunchKernelGGL(im2col_patch_kernel, dim3(grid_for(total)), dim3(256), 0, stream, rgb, dsm, (bf16_t*)cols, (int)B, (int)H, (int)W, (int)P, dsm_channels);
   MF_LAUNCH_CHECK("im2col_patch");
   return MFNET_OK;
 }

@@ -161,9 +161,7 @@ class FpnFusionFn(torch.autograd.Function):
             fu = getattr(model, f"fusion{i + 1}")
             gate = {}
             for m, se in (("x", fu.se_rgb), ("y", fu.se_depth)):
-                s, _ = ops.colsum(r[m][i], B, P[i])
-                z, g = ops.se_gate_fwd(s, P[i], _w2(se.fc[0].weight), se.fc[0].bias, _w2(se.fc[2].weight), se.fc[2].bias, False)
-                gate[m] = (s, z, g)
+                gate[m] = se_gates(se, r[m][i], B, P[i])
             outs.append(ops.se_scale_sum(r["x"][i], r["y"][i], gate["x"][2], gate["y"][2], B, P[i]))
             sv[f"f{i}"] = gate
         sv["r"], sv["P"] = r, P
@@ -264,6 +262,80 @@ def block_params(blk):
             blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias]
 
 
+def _reflect_index(n, npad, device):
+    i = torch.arange(npad, device=device)
+    return torch.where(i < n, i, 2 * n - 2 - i)
+
+
+def _reflect_rows(t, B, H, W, Hp, Wp):
+    """channels-last rows [B*H*W, C] -> [B*Hp*Wp, C], reflect-padded at the bottom / right like F.pad(mode='reflect')."""
+    C = t.shape[-1]
+    v = t.view(B, H, W, C)
+    if Hp != H:
+        v = v.index_select(1, _reflect_index(H, Hp, t.device))
+    if Wp != W:
+        v = v.index_select(2, _reflect_index(W, Wp, t.device))
+    return v.contiguous().view(B * Hp * Wp, C)
+
+
+def _reflect_rows_bwd(dp, B, H, W, Hp, Wp):
+    """adjoint of _reflect_rows: the padded rows' gradients are added onto the rows they mirror (fp32 sums, bf16 result)."""
+    C = dp.shape[-1]
+    v = dp.view(B, Hp, Wp, C).float()
+    if Wp != W:
+        v = torch.zeros((B, Hp, W, C), dtype=torch.float32, device=dp.device).index_add_(2, _reflect_index(W, Wp, dp.device), v)
+    if Hp != H:
+        v = torch.zeros((B, H, W, C), dtype=torch.float32, device=dp.device).index_add_(1, _reflect_index(H, Hp, dp.device), v)
+    return v.to(dp.dtype).contiguous().view(B * H * W, C)
+
+
+def gla_forward(a, n1b, geom, training, residual=None):
+    """GlobalLocalAttention.forward (unetformer_mmsam.py:161-198) on bf16 channels-last rows n1b [B*H*W, C]:
+    local = BN(conv3x3) + BN(conv1x1); 8x8-window attention with the relative-position bias on the (reflect-padded) map;
+    avg-pool (ws,1) + (1,ws) of it; + local; reflect-pad by one, depthwise ws x ws, BN, 1x1 (+ residual).
+    -> (out fp32 [B*H*W, C], tensors the backward needs)."""
+    B, H, W = geom
+    heads, ws = a.num_heads, a.ws
+    Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
+    if Hp - H >= H or Wp - W >= W:
+        raise ValueError(f"GlobalLocalAttention: a {H}x{W} map cannot be reflect-padded to the {ws}x{ws} window grid "
+                         "(F.pad(mode='reflect') needs pad < size, unetformer_mmsam.py:149-155)")
+    c1, cols = _conv3_fwd(n1b, a.local1[0].weight, B, H, W)
+    l1, _, ml1, rl1 = _bn(c1, a.local1[1], training)
+    c2 = ops.gemm(n1b, _wb(_w2(a.local2[0].weight)), out_dtype=F32)
+    l2, _, ml2, rl2 = _bn(c2, a.local2[1], training)
+    qkv = ops.gemm(n1b, _wb(_w2(a.qkv[0].weight)))
+    table = a.relative_position_bias_table.detach().contiguous()
+    if (Hp, Wp) == (H, W):
+        o = ops.gla_attn_fwd(qkv, table, B, H, W, heads, a.scale)
+    else:
+        # pad() branch (:149-155, :166): the map is reflect-padded to whole windows BEFORE the 1x1 qkv conv; the conv is
+        # pointwise, so padding its output rows is the same thing. Row gather (data movement only), window attention on
+        # the padded grid, crop (:187).
+        qkv_p = _reflect_rows(qkv, B, H, W, Hp, Wp)
+        o = ops.gla_attn_fwd(qkv_p, table, B, Hp, Wp, heads, a.scale)
+        o = o.view(B, Hp, Wp, -1)[:, :H, :W].contiguous().view(B * H * W, -1)
+    s = ops.gla_pool_fwd(o, l1, l2, B, H, W)
+    k = a.proj[0].weight.shape[-1]
+    dwo = ops.dwconv_fwd(s, a.proj[0].weight.detach().reshape(-1, k * k), None, B, H, W, k, True)
+    pb, _, mp, rp = _bn(dwo, a.proj[1], training, out_dtype=BF)
+    out = ops.gemm(pb, _wb(_w2(a.proj[2].weight)), residual=residual, out_dtype=F32)
+    return out, (cols, c1, ml1, rl1, c2, ml2, rl2, qkv, s, dwo, mp, rp, pb)
+
+
+def mlp_forward(mlp, n2b, residual=None):
+    """Mlp (unetformer_mmsam.py:86-102, drop=0): fc2(ReLU6(fc1(.))) as two GEMMs with fused bias / activation."""
+    hid = ops.gemm(n2b, _wb(_w2(mlp.fc1.weight)), bias=mlp.fc1.bias, act=3)
+    return ops.gemm(hid, _wb(_w2(mlp.fc2.weight)), bias=mlp.fc2.bias, residual=residual, out_dtype=F32), hid
+
+
+def se_gates(se, rows, B, P):
+    """SqueezeAndExcitation's per-(image, channel) gate (unetformer_mmsam.py:251-266): sigmoid(fc2(ReLU(fc1(mean))))."""
+    s, _ = ops.colsum(rows, B, P)
+    z, g = ops.se_gate_fwd(s, P, _w2(se.fc[0].weight), se.fc[0].bias, _w2(se.fc[2].weight), se.fc[2].bias, False)
+    return s, z, g
+
+
 class BlockFn(torch.autograd.Function):
     """Block (unetformer_mmsam.py:200-217) = x + GlobalLocalAttention(BN(x)) (:105-198), then + Mlp(BN(.))
     (:86-102). x fp32 [B*H*W, C] -> fp32."""
@@ -273,26 +345,10 @@ class BlockFn(torch.autograd.Function):
         B, H, W = geom
         a = blk.attn
         x = x.contiguous()
-        heads, ws = a.num_heads, a.ws
-        if H % ws or W % ws:
-            raise NotImplementedError(f"GlobalLocalAttention on a {H}x{W} map: the HIP path needs multiples of the {ws}x{ws} window "
-                                      "(input tiles that are multiples of 256 pixels); the reflect-pad branch is not implemented")
         n1b, _, m1, r1 = _bn(x, blk.norm1, training, out_dtype=BF)
-        c1, cols = _conv3_fwd(n1b, a.local1[0].weight, B, H, W)
-        l1, _, ml1, rl1 = _bn(c1, a.local1[1], training)
-        c2 = ops.gemm(n1b, _wb(_w2(a.local2[0].weight)), out_dtype=F32)
-        l2, _, ml2, rl2 = _bn(c2, a.local2[1], training)
-        qkv = ops.gemm(n1b, _wb(_w2(a.qkv[0].weight)))
-        table = a.relative_position_bias_table.detach().contiguous()
-        o = ops.gla_attn_fwd(qkv, table, B, H, W, heads, a.scale)
-        s = ops.gla_pool_fwd(o, l1, l2, B, H, W)
-        k = a.proj[0].weight.shape[-1]
-        dwo = ops.dwconv_fwd(s, a.proj[0].weight.detach().reshape(-1, k * k), None, B, H, W, k, True)
-        pb, _, mp, rp = _bn(dwo, a.proj[1], training, out_dtype=BF)
-        x1 = ops.gemm(pb, _wb(_w2(a.proj[2].weight)), residual=x, out_dtype=F32)
+        x1, (cols, c1, ml1, rl1, c2, ml2, rl2, qkv, s, dwo, mp, rp, pb) = gla_forward(a, n1b, geom, training, residual=x)
         n2b, _, m2, r2 = _bn(x1, blk.norm2, training, out_dtype=BF)
-        hid = ops.gemm(n2b, _wb(_w2(blk.mlp.fc1.weight)), bias=blk.mlp.fc1.bias, act=3)
-        x2 = ops.gemm(hid, _wb(_w2(blk.mlp.fc2.weight)), bias=blk.mlp.fc2.bias, residual=x1, out_dtype=F32)
+        x2, hid = mlp_forward(blk.mlp, n2b, residual=x1)
         ctx.save_for_backward(x, m1, r1, n1b, cols, c1, ml1, rl1, c2, ml2, rl2, qkv, s, dwo, mp, rp, pb, x1, m2, r2, n2b, hid)
         ctx.blk, ctx.geom, ctx.training, ctx.plist = blk, geom, training, plist
         return x2
@@ -324,7 +380,16 @@ class BlockFn(torch.autograd.Function):
         _put(gd, a.proj[0].weight, dwdw)
         d_o = ops.gla_pool_bwd(ds, B, H, W)
         table = a.relative_position_bias_table.detach().contiguous()
-        dqkv, dtable = ops.gla_attn_bwd(qkv, table, d_o, B, H, W, a.num_heads, a.scale)
+        ws = a.ws
+        Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
+        if (Hp, Wp) == (H, W):
+            dqkv, dtable = ops.gla_attn_bwd(qkv, table, d_o, B, H, W, a.num_heads, a.scale)
+        else:
+            C = d_o.shape[-1]
+            d_op = torch.zeros((B, Hp, Wp, C), dtype=d_o.dtype, device=d_o.device)          # cropped rows receive no gradient
+            d_op[:, :H, :W] = d_o.view(B, H, W, C)
+            dqkv_p, dtable = ops.gla_attn_bwd(_reflect_rows(qkv, B, H, W, Hp, Wp), table, d_op.view(-1, C), B, Hp, Wp, a.num_heads, a.scale)
+            dqkv = _reflect_rows_bwd(dqkv_p, B, H, W, Hp, Wp)
         _put(gd, a.relative_position_bias_table, dtable)
         dc1, dg, dbt = _bn_bwd(ds, c1, ml1, rl1, a.local1[1], training, dx_dtype=BF)
         _put(gd, a.local1[1].weight, dg); _put(gd, a.local1[1].bias, dbt)

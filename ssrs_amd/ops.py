@@ -314,13 +314,33 @@ def bf16_of(d2):
     return cast(d2, torch.bfloat16)
 
 
+def gelu_fwd(x):
+    """erf GELU on an fp32 tensor (standalone MLPBlock forwards; the blocks fuse it into the GEMM epilogue)."""
+    _chk(x)
+    assert x.is_contiguous() and x.dtype == torch.float32
+    y = torch.empty_like(x)
+    call("mfnet_gelu_fwd", x.data_ptr(), y.data_ptr(), x.numel(), _stream(x))
+    return y
+
+
+def gelu_bwd(x, dy):
+    _chk(x, dy)
+    assert x.is_contiguous() and dy.is_contiguous() and x.dtype == torch.float32 and dy.dtype == torch.float32
+    dx = torch.empty_like(x)
+    call("mfnet_gelu_bwd", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), _stream(x))
+    return dx
+
+
 def im2col_patch(rgb, dsm, patch=16):
-    """rgb [B,3,H,W] fp32, dsm [B,H,W] fp32 -> [2*B*(H/P)*(W/P), 3*P*P] bf16 (rgb rows first)."""
+    """rgb [B,3,H,W] fp32, dsm [B,H,W] (one plane, replicated) or [B,3,H,W] fp32 -> [2*B*(H/P)*(W/P), 3*P*P] bf16 (rgb rows first)."""
     _chk(rgb, dsm)
     assert rgb.is_contiguous() and dsm.is_contiguous() and rgb.dtype == torch.float32 and dsm.dtype == torch.float32
     B, _, H, W = rgb.shape
+    ych = 1 if dsm.dim() == 3 else int(dsm.shape[1])
+    if tuple(dsm.shape) != ((B, H, W) if dsm.dim() == 3 else (B, ych, H, W)) or rgb.shape[1] != 3 or ych not in (1, 3):
+        raise ValueError(f"im2col_patch: rgb {tuple(rgb.shape)} and second modality {tuple(dsm.shape)} do not match")
     cols = torch.empty((2 * B * (H // patch) * (W // patch), 3 * patch * patch), dtype=torch.bfloat16, device=rgb.device)
-    call("mfnet_im2col_patch", rgb.data_ptr(), dsm.data_ptr(), cols.data_ptr(), B, H, W, patch, _stream(rgb))
+    call("mfnet_im2col_patch", rgb.data_ptr(), dsm.data_ptr(), ych, cols.data_ptr(), B, H, W, patch, _stream(rgb))
     return cols
 
 

@@ -24,9 +24,10 @@ from .medsam import cfg
 from .sam import sam_model_registry
 
 
-def _fused_only(name):
-    raise NotImplementedError(f"{name} has no standalone forward in the HIP path: it is computed inside the fused "
-                              "Block / FpnFusion functions of ssrs_amd/decoder_ops.py")
+# Standalone forwards of the sub-modules (Mlp, GlobalLocalAttention, SqueezeAndExcitation, SEFusion): the same kernels the
+# fused Block / FpnFusion functions run, for callers that use a module on its own (feature inspection, unit tests, reuse in
+# another head). They are FORWARD-ONLY - computed under no_grad; training goes through the fused autograd functions, which
+# own the hand-written backward.
 
 
 class Norm2d(nn.Module):
@@ -75,8 +76,12 @@ class Mlp(nn.Module):
         self.act = nn.ReLU6()
         self.fc2 = nn.Conv2d(hidden, dim, 1, 1, 0, bias=True)
 
+    @torch.no_grad()
     def forward(self, x):
-        _fused_only("Mlp")
+        """unetformer_mmsam.py:96-102 (forward only)."""
+        B, _, H, W = x.shape
+        out, _ = D.mlp_forward(self, D.to_rows(x, torch.bfloat16))
+        return D.to_nchw(out, B, H, W)
 
 
 class GlobalLocalAttention(nn.Module):
@@ -102,8 +107,12 @@ class GlobalLocalAttention(nn.Module):
             self.register_buffer("relative_position_index", rel.sum(-1))
             nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
 
+    @torch.no_grad()
     def forward(self, x):
-        _fused_only("GlobalLocalAttention")
+        """unetformer_mmsam.py:161-198 (forward only; BatchNorm follows self.training, running statistics included)."""
+        B, _, H, W = x.shape
+        out, _ = D.gla_forward(self, D.to_rows(x, torch.bfloat16), (B, H, W), self.training)
+        return D.to_nchw(out, B, H, W)
 
 
 class Block(nn.Module):
@@ -174,8 +183,16 @@ class SqueezeAndExcitation(nn.Module):
         self.fc = nn.Sequential(nn.Conv2d(channel, channel // reduction, kernel_size=1), activation,
                                 nn.Conv2d(channel // reduction, channel, kernel_size=1), nn.Sigmoid())
 
+    @torch.no_grad()
     def forward(self, x):
-        _fused_only("SqueezeAndExcitation")
+        """unetformer_mmsam.py:262-266 (forward only): x * sigmoid(fc2(act(fc1(mean_hw(x)))))."""
+        if not isinstance(self.fc[1], nn.ReLU):
+            raise NotImplementedError("the HIP gate kernel implements the ReLU MFNet uses")
+        B, _, H, W = x.shape
+        rows = D.to_rows(x.float())
+        _, _, g = D.se_gates(self, rows, B, H * W)
+        out = D.ops.se_scale_sum(rows, rows, g, torch.zeros_like(g), B, H * W, out_dtype=torch.float32)
+        return D.to_nchw(out, B, H, W)
 
 
 class SEFusion(nn.Module):
@@ -184,8 +201,13 @@ class SEFusion(nn.Module):
         self.se_rgb = SqueezeAndExcitation(channels_in, activation=activation)
         self.se_depth = SqueezeAndExcitation(channels_in, activation=activation)
 
+    @torch.no_grad()
     def forward(self, rgb, depth):
-        _fused_only("SEFusion")
+        """unetformer_mmsam.py:276-281 (forward only): se_rgb(rgb) + se_depth(depth)."""
+        B, _, H, W = rgb.shape
+        rx, ry = D.to_rows(rgb.float()), D.to_rows(depth.float())
+        gx, gy = D.se_gates(self.se_rgb, rx, B, H * W)[2], D.se_gates(self.se_depth, ry, B, H * W)[2]
+        return D.to_nchw(D.ops.se_scale_sum(rx, ry, gx, gy, B, H * W, out_dtype=torch.float32), B, H, W)
 
 
 class Decoder(nn.Module):

@@ -417,6 +417,24 @@ class MergedLinear(nn.Linear, LoRALayer):
             for a in (self.lora_Ax, self.lora_Ay):
                 nn.init.kaiming_uniform_(a, a=math.sqrt(5))
 
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, y: torch.Tensor):
+        """layers.py:244-268, forward only (training runs through _LoraAttnBranch, which owns the backward): both
+        modalities in one GEMM launch whose epilogue adds the per-modality rank-r update of the q and v thirds."""
+        h = torch.stack([x, y])
+        K = h.shape[-1]
+        M = h.numel() // K
+        xb = ops.cast(h.reshape(M, K).contiguous().float(), BF)
+        if self.r > 0:
+            a = _down(xb, self.lora_Ax, self.lora_Ay, M // 2)
+            V = _qkv_lora_V(self.lora_Bx, self.lora_By, self.out_features // 3, self.r)
+            out = ops.gemm(xb, w_bf16(self.weight), bias=self.bias, U=a, V=V, rows_per_group=M // 2, n_groups=2,
+                           lr_scale=self.scaling, out_dtype=torch.float32)
+        else:
+            out = ops.gemm(xb, w_bf16(self.weight), bias=self.bias, out_dtype=torch.float32)
+        out = out.view(*h.shape[:-1], -1)
+        return out[0], out[1]
+
 
 class Adapter(nn.Module):
     """common/adapter.py:7-25."""
@@ -428,6 +446,18 @@ class Adapter(nn.Module):
         self.act = act_layer()
         self.D_fc1 = nn.Linear(D_features, D_hidden)
         self.D_fc2 = nn.Linear(D_hidden, D_features)
+
+    @torch.no_grad()
+    def forward(self, x):
+        """adapter.py:16-25, forward only (AdapterFusionBlock's fused branches own the backward): fc2(GELU(fc1(x))) (+ x)."""
+        if not isinstance(self.act, nn.GELU):
+            raise NotImplementedError("the HIP epilogue implements the erf GELU MFNet uses")
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K).contiguous().float()
+        hid = ops.gemm(ops.cast(x2, BF), w_bf16(self.D_fc1.weight), bias=self.D_fc1.bias, act=1)
+        out = ops.gemm(hid, w_bf16(self.D_fc2.weight), bias=self.D_fc2.bias, residual=x2 if self.skip_connect else None,
+                       out_dtype=torch.float32)
+        return out.view(x.shape)
 
 
 class LayerNorm2d(nn.Module):
@@ -447,12 +477,33 @@ class LayerNorm2d(nn.Module):
 # ---------------------------------------------------------------------------------------------
 # blocks
 # ---------------------------------------------------------------------------------------------
+class _Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous().float()
+        ctx.save_for_backward(x)
+        return ops.gelu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.gelu_bwd(ctx.saved_tensors[0], dy.contiguous().float())
+
+
+_gelu = _Gelu.apply
+
+
 class MLPBlock(nn.Module):
     def __init__(self, embedding_dim: int, mlp_dim: int, act: Type[nn.Module] = nn.GELU, lora_rank: int = 4) -> None:
         super().__init__()
         self.lin1 = Linear(embedding_dim, mlp_dim, r=lora_rank)
         self.lin2 = Linear(mlp_dim, embedding_dim, r=lora_rank)
         self.act = act()
+
+    def forward(self, x: torch.Tensor, y: torch.Tensor):
+        """lora_block.py:104-108 (standalone; the block fuses it into _LoraMlpBranch)."""
+        x, y = self.lin1(x, y)
+        x, y = _gelu(x), _gelu(y)
+        return self.lin2(x, y)
 
 
 class Attention(nn.Module):
@@ -569,7 +620,8 @@ class ImageEncoderViT(nn.Module):
         ).permute(0, 2, 3, 1).reshape(Sh * Sw, -1).contiguous())
 
     def embed(self, rgb: torch.Tensor, dsm: torch.Tensor) -> torch.Tensor:
-        """patch-embed both modalities (DSM replicated to 3 channels by the im2col) + abs-pos add
+        """patch-embed both modalities (a (B,H,W) DSM plane is replicated to 3 channels by the im2col; a (B,3,H,W) second
+        modality is read as it is) + abs-pos add
         -> stacked residual stream [2, B, Sh, Sw, D] fp32."""
         B, _, H, W = rgb.shape
         P = self.patch_size
@@ -592,14 +644,10 @@ class ImageEncoderViT(nn.Module):
         return _Neck.apply(h.view(2 * B, Sh, Sw, D), self)          # [2B, Sh, Sw, C] channels-last
 
     def forward(self, x: torch.Tensor, y: torch.Tensor):
-        """x, y: (B,3,H,W). The reference feeds y = DSM repeated to 3 channels (unetformer_mmsam.py:535);
-        the shared patch-embed is linear, so a general 3-channel y is handled by the same kernel only
-        when its channels are identical - otherwise it is embedded as a second RGB batch."""
+        """x, y: (B,3,H,W) (image_encoder.py:122-144). MFNet feeds y = the DSM repeated to 3 channels
+        (unetformer_mmsam.py:535) and calls forward_stacked with the plane itself; here y is taken as the 3-channel image
+        the interface promises - the patch gather reads its own channels, no host-side check of the data."""
         B = x.shape[0]
-        if y.dim() == 4 and bool((y[:, :1] == y).all()):
-            out = self.forward_stacked(x, y[:, 0])
-        else:
-            raise NotImplementedError("ImageEncoderViT.forward needs y = a single channel repeated 3x (the DSM/NIR "
-                                      "modality as MFNet feeds it); pass the (B,H,W) plane via forward_stacked")
+        out = self.forward_stacked(x, y)
         fx, fy = out[:B], out[B:]
         return fx.permute(0, 3, 1, 2), fy.permute(0, 3, 1, 2)

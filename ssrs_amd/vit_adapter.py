@@ -41,6 +41,14 @@ class MLPBlock(nn.Module):
         self.lin2 = nn.Linear(mlp_dim, embedding_dim)
         self.act = act()
 
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """adapter_fusionblock.py:128-139, forward only (frozen weights; the block fuses it into _AdapterMlpBranch)."""
+        K = x.shape[-1]
+        xb = ops.cast(x.reshape(-1, K).contiguous().float(), BF)
+        hid = ops.gemm(xb, w_bf16(self.lin1.weight), bias=self.lin1.bias, act=1)
+        return ops.gemm(hid, w_bf16(self.lin2.weight), bias=self.lin2.bias, out_dtype=torch.float32).view(*x.shape[:-1], -1)
+
 
 # ---- trainable per-modality dense layer pair (x rows use (Wx, bx), y rows (Wy, by)): forward + (dgrad, wgrad, bias grad)
 def _w2(Wx, Wy, transpose=False):

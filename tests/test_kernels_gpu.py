@@ -283,6 +283,11 @@ def test_im2col_patch_and_3x3(ops):
     both = torch.cat([rgb, dsm[:, None].repeat(1, 3, 1, 1)])
     ref = F.unfold(both, 16, stride=16).transpose(1, 2).reshape(-1, 768)
     assert torch.equal(cols.float(), bf16r(ref))
+    y3 = rnd(B, 3, H, W, seed=5)                                    # a real 3-channel second modality
+    ref = F.unfold(torch.cat([rgb, y3]), 16, stride=16).transpose(1, 2).reshape(-1, 768)
+    assert torch.equal(ops.im2col_patch(rgb, y3, 16).float(), bf16r(ref))
+    with pytest.raises(ValueError):
+        ops.im2col_patch(rgb, rnd(B, 2, H, W, seed=6), 16)
     G, S, C = 3, 10, 64
     x = rnd(G, S, S, C, seed=3).to(torch.bfloat16)
     c3 = ops.im2col3x3(x, G, S, S)

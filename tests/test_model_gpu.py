@@ -263,6 +263,65 @@ def test_full_size_train_steps_run_and_learn(mod, encoder, tile, batch):
     assert torch.isfinite(eng.flat_g).all() and eng.flat_g.abs().sum() > 0
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_engine_checkpoint_round_trip(use_graph):
+    """resume = the weights file of the reference (model.state_dict(), trainer.py:379-394) + TrainEngine.state_dict()
+    (momentum, epoch, step count): a fresh model + engine loaded from both continues exactly like the one that kept
+    running - same losses, same parameters, same BatchNorm statistics. Both files go through torch.save / torch.load
+    (weights_only=True), the way Trainer writes and reads them."""
+    import io
+    from ssrs_amd.trainer import TrainEngine
+    fill = detfill.fill_state_dict(_tiny_model("sam_lora").state_dict(), "ckpt/")
+    rgb, dsm, tgt = [t.cuda() for t in detfill.tiles("ckpt", 2, 256, 6)]
+
+    def make():
+        m = _tiny_model("sam_lora")
+        m.load_state_dict(fill)
+        m = m.cuda().train()
+        m.decoder.segmentation_head[1].p = 0.0          # Dropout2d draws from the global RNG; not what is under test
+        return m, TrainEngine(m, lr=0.01, momentum=0.9, weight_decay=5e-4, class_weight=torch.ones(6, device="cuda"), use_graph=use_graph)
+
+    def run(eng, n):
+        return [TrainEngine.read_metrics(eng.step(rgb, dsm, tgt))["loss"] for _ in range(n)]
+
+    m1, e1 = make()
+    run(e1, 3)
+    buf_w, buf_o = io.BytesIO(), io.BytesIO()
+    torch.save(m1.state_dict(), buf_w)
+    torch.save(e1.state_dict(), buf_o)
+    saved_w = {k: v.clone() for k, v in m1.state_dict().items()}
+    saved_m = e1.flat_m.clone()
+    cont = run(e1, 3)
+    m2, e2 = make()
+    buf_w.seek(0); buf_o.seek(0)
+    m2.load_state_dict(torch.load(buf_w, map_location="cuda", weights_only=True))
+    e2.load_state_dict(torch.load(buf_o, map_location="cuda", weights_only=True))
+    # the restored state is the saved state, bit for bit: every parameter and buffer (BatchNorm statistics and counters
+    # included), the momentum buffer, the step / epoch counters and with them the learning rate
+    assert e2.steps == 3 and e2.epoch == e1.epoch and e2.lr == e1.lr
+    sd2 = m2.state_dict()
+    assert all(torch.equal(sd2[k], v) for k, v in saved_w.items())
+    assert torch.equal(e2.flat_m, saved_m)
+    resumed = run(e2, 3)
+    # ... and it continues like the engine that kept running. The first loss agrees to fp32 noise. Later steps agree to
+    # bf16 level only, as ANY two runs of this step do: fp32 atomics order leaves 1-ulp differences in a few weights after
+    # an update, and each bf16 rounding of an intermediate turns a perturbation d into sqrt(d * ulp_bf16) RMS (measured:
+    # identical logits, gradients 4e-3 apart after a 1-ulp change of 8 weights; tools/grad_noise.py). A resume
+    # that lost the momentum is another order of magnitude away (control below).
+    assert abs(cont[0] - resumed[0]) < 5e-6 * cont[0], (cont, resumed)
+    assert np.allclose(cont, resumed, rtol=2e-3, atol=0), (cont, resumed)
+    assert cont[-1] < cont[0]
+    m3, e3 = make()
+    buf_w.seek(0)
+    m3.load_state_dict(torch.load(buf_w, map_location="cuda", weights_only=True))
+    cold = run(e3, 3)                       # weights only (what the reference saves): NOT the same continuation
+    assert abs(cold[-1] - cont[-1]) > 10 * abs(resumed[-1] - cont[-1]) and abs(cold[-1] - cont[-1]) > 5e-3 * cont[-1], (cont, resumed, cold)
+    with pytest.raises(ValueError):
+        bad = e1.state_dict()
+        bad["names"] = bad["names"][1:]
+        e2.load_state_dict(bad)
+
+
 def test_cpu_tensors_are_rejected_loudly():
     from ssrs_amd._lib import MfnetError
     m = _tiny_model("sam_lora")
