@@ -412,6 +412,31 @@ int mfnet_blend_finish(const float* sum, const float* cnt, float* prob, unsigned
  * pred uint8, gt int64, cm int64 [n,n] (zero first), n <= 32. */
 int mfnet_confusion(const unsigned char* pred, const int64_t* gt, int64_t* cm, int64_t n_classes, int64_t total, hipStream_t stream);
 
+/* ---- fp32-accurate forward path (csrc/fp32.hip): the reference's arithmetic is fp32 throughout (unetformer_mmsam.py:533-563,
+ * lora_block.py:169-196); these entry points reproduce its logits to 1e-4 relative where the bf16 MFMA path gives 2e-2.
+ * Inference / evaluation forward only.
+ *
+ * gemm_f32: out[m,n] = act(alpha * sum_k A[m,k] W[n,k] + bias[n]) (+ residual[m or m % res_row_mod, n]) (+ out[m,n] if accumulate),
+ * all fp32, on v_mfma_f32_16x16x4_f32 (a k-ordered fp32 fma chain) - what F.linear / 1x1 convs / im2col'ed 3x3 convs and the
+ * rank-r LoRA products (layers.py:149-165, 244-268) compute. K % 4 == 0, lda / ldw % 4 == 0, 16-byte aligned operands.
+ * act: 0 none, 1 GELU (erf), 3 ReLU6, 6 ReLU.
+ * attn_f32: SAM ViT attention (lora_block.py:169-196, adapter_fusionblock.py:142-198) on qkv [G*Sh*Sw, 3*heads*hd] fp32:
+ * ws > 0 = ws x ws windows over the zero-padded map (a padded token's qkv row is qkv_bias, lora_block.py:199-220), ws == 0 =
+ * global; scores = scale * q.k + q.th[qy-ky+kh-1] + q.tw[qx-kx+kw-1] with the resized tables th [2kh-1, hd], tw [2kw-1, hd]
+ * (get_rel_pos / add_decomposed_rel_pos, :248-317); out [G*Sh*Sw, heads*hd]. hd in {32, 64, 80}; window / map side <= 64.
+ * im2col_patch_f32 / im2col3x3_f32: fp32 twins of mfnet_im2col_patch / mfnet_im2col3x3. gla_attn_fwd_f32: mfnet_gla_attn_fwd
+ * on fp32 qkv. */
+int mfnet_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, int64_t M, int64_t N, int64_t K, const float* bias,
+                   float alpha, int act, const float* residual, int64_t ldr, int64_t res_row_mod, float* out, int64_t ldo,
+                   int accumulate, hipStream_t stream);
+int mfnet_attn_f32(const float* qkv, const float* qkv_bias, const float* th, const float* tw, float* out, int64_t G, int64_t Sh,
+                   int64_t Sw, int64_t heads, int64_t hd, int64_t ws, float scale, hipStream_t stream);
+int mfnet_im2col_patch_f32(const float* rgb, const float* dsm, int dsm_channels, float* cols, int64_t B, int64_t H, int64_t W,
+                           int64_t P, hipStream_t stream);
+int mfnet_im2col3x3_f32(const float* x, float* cols, int64_t G, int64_t H, int64_t W, int64_t C, hipStream_t stream);
+int mfnet_gla_attn_fwd_f32(const float* qkv, const float* table, float* out, int64_t B, int64_t H, int64_t W, int64_t heads,
+                           int64_t hd, int64_t ws, float scale, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

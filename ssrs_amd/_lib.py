@@ -107,6 +107,12 @@ _SIGS = {
     "mfnet_normalize_raster": [P, I, I64, I64, I64, I, I, F, F, P, P, I, D, P, P, P],
     "mfnet_tile_prob_mask": [P, P, P, P, I64, I64, I64, I64, I64, F, P],
     "mfnet_confusion": [P, P, P, I64, I64, P],
+    # ---- fp32-accurate forward path (csrc/fp32.hip)
+    "mfnet_gemm_f32": [P, I64, P, I64, I64, I64, I64, P, F, I, P, I64, I64, P, I64, I, P],
+    "mfnet_attn_f32": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, F, P],
+    "mfnet_im2col_patch_f32": [P, P, I, P, I64, I64, I64, I64, P],
+    "mfnet_im2col3x3_f32": [P, P, I64, I64, I64, I64, P],
+    "mfnet_gla_attn_fwd_f32": [P, P, P, I64, I64, I64, I64, I64, I64, F, P],
 }
 
 

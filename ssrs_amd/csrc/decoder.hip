@@ -757,7 +757,12 @@ __device__ __forceinline__ void gla_ld8(const bf16_t* p, float* o) {
   o[0] = bf16_lo(v.x); o[1] = bf16_hi(v.x); o[2] = bf16_lo(v.y); o[3] = bf16_hi(v.y);
   o[4] = bf16_lo(v.z); o[5] = bf16_hi(v.z); o[6] = bf16_lo(v.w); o[7] = bf16_hi(v.w);
 }
-__global__ __launch_bounds__(256) void gla_attn_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ table,
+__device__ __forceinline__ void gla_ld8(const float* p, float* o) {          // fp32-accurate forward path: qkv kept in fp32
+  const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gla_attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ table,
                                                            float* __restrict__ out, const GlaParams p) {
   __shared__ float kl[4][64][GLA_HD + 1], vl[4][64][GLA_HD + 1];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -918,8 +923,19 @@ extern "C" int mfnet_gla_attn_fwd(const void* qkv, const float* table, float* ou
   int rc = gla_check(&p, B, H, W, heads, hd, ws, scale, "gla_attn_fwd");
   if (rc) return rc;
   const int64_t nwin = B * (H / GLA_WS) * (W / GLA_WS);
-  hipLaunchKernelGGL(gla_attn_fwd_kernel, dim3((unsigned)nwin, (unsigned)ceil_div64(heads, 4)), dim3(256), 0, stream, (const bf16_t*)qkv, table, out, p);
+  hipLaunchKernelGGL(gla_attn_fwd_kernel<bf16_t>, dim3((unsigned)nwin, (unsigned)ceil_div64(heads, 4)), dim3(256), 0, stream, (const bf16_t*)qkv, table, out, p);
   MF_LAUNCH_CHECK("gla_attn_fwd");
+  return MFNET_OK;
+}
+extern "C" int mfnet_gla_attn_fwd_f32(const float* qkv, const float* table, float* out, int64_t B, int64_t H, int64_t W, int64_t heads,
+                                      int64_t hd, int64_t ws, float scale, hipStream_t stream) {
+  MF_CHECK_ARG(qkv && table && out, "gla_attn_fwd_f32: null pointer");
+  GlaParams p;
+  int rc = gla_check(&p, B, H, W, heads, hd, ws, scale, "gla_attn_fwd_f32");
+  if (rc) return rc;
+  const int64_t nwin = B * (H / GLA_WS) * (W / GLA_WS);
+  hipLaunchKernelGGL(gla_attn_fwd_kernel<float>, dim3((unsigned)nwin, (unsigned)ceil_div64(heads, 4)), dim3(256), 0, stream, qkv, table, out, p);
+  MF_LAUNCH_CHECK("gla_attn_fwd_f32");
   return MFNET_OK;
 }
 extern "C" int mfnet_gla_attn_bwd(const void* qkv, const float* table, const float* dout, void* dqkv, float* dtable, int64_t B, int64_t H,

@@ -254,14 +254,20 @@ class UNetFormer(nn.Module):
     """MFNet. Extra keyword arguments (not in the reference, all optional): `encoder` selects the SAM
     size ('vit_b' | 'vit_l' | 'vit_h'; the reference hard-codes 'vit_l' and is edited by hand,
     unetformer_mmsam.py:488-490; env MFNET_ENCODER overrides the default), `sam_checkpoint` the local
-    .pth, `args` a pre-parsed cfg namespace instead of sys.argv."""
+    .pth, `args` a pre-parsed cfg namespace instead of sys.argv, `precision` 'bf16' | 'fp32' (see __init__)."""
 
     _CKPT = {"vit_b": "weights/sam_vit_b_01ec64.pth", "vit_l": "weights/sam_vit_l_0b3195.pth",
              "vit_h": "weights/sam_vit_h_4b8939.pth", "default": "weights/sam_vit_b_01ec64.pth"}
 
     def __init__(self, decode_channels=64, dropout=0.1, window_size=8, num_classes=6, *, encoder=None,
-                 sam_checkpoint=None, args=None):
+                 sam_checkpoint=None, args=None, precision=None):
         super().__init__()
+        # "bf16" (default): bf16 MFMA contractions with fp32 accumulation, training + inference, logits within 2e-2 of the fp32
+        # reference. "fp32": every contraction on the fp32 MFMA, fp32 activations, logits within 1e-4 - eval forward only
+        # (ssrs_amd/fp32_path.py). May be switched on a built model: model.precision = "fp32".
+        self.precision = precision or os.environ.get("MFNET_PRECISION", "bf16")
+        if self.precision not in ("bf16", "fp32"):
+            raise ValueError(f"precision {self.precision!r}: 'bf16' or 'fp32'")
         if args is None:
             args = cfg.parse_args()
         encoder = encoder or os.environ.get("MFNET_ENCODER", "vit_l")
@@ -296,6 +302,9 @@ class UNetFormer(nn.Module):
         self.decoder = Decoder(ec, decode_channels, dropout, window_size, num_classes)
 
     def forward(self, x, y, mode='Train'):
+        if self.precision == "fp32":
+            from .fp32_path import forward_fp32
+            return forward_fp32(self, x, y)
         h, w = x.shape[-2:]
         B = x.shape[0]
         deep = self.image_encoder.forward_stacked(x, y)             # [2B, H/16, W/16, 256] channels-last

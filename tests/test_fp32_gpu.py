@@ -1,0 +1,143 @@
+"""The fp32-accurate forward path (north star: "logits must agree within 1e-4 relative for the fp32 path").
+
+Kernels (through the C ABI) against float64 torch on the same inputs at 1e-5; whole models (tiny MMLoRA / MMAdapter, ViT-B
+MMLoRA / MMAdapter at the BASELINE tile size) against the goldens the reference itself produced in float64 arithmetic
+(tools/make_goldens.py) at 1e-4 relative (max |a-b| / max |b|) and argmax agreement >= 99.9 %."""
+import argparse
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import golden, rel_err
+from oracle import mfnet_ref as R
+from ssrs_amd import detfill
+
+pytestmark = pytest.mark.gpu
+FP32_TOL = 1e-4
+
+
+def _u(key, shape, scale=1.0):
+    return torch.from_numpy(detfill.uniform(key, shape)).float() * scale
+
+
+def _args(mod):
+    return argparse.Namespace(mod=mod, mid_dim=None, image_size=1024, multimask_output=1)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 768, 768), (100, 6, 64), (392, 2304, 768), (70, 68, 4), (64, 64, 36), (1, 8, 768)])
+def test_gemm_f32_all_epilogues(M, N, K):
+    from ssrs_amd.fp32_path import gemm32
+    a, w, b = _u("g32/a", (M, K)), _u("g32/w", (N, K)), _u("g32/b", (N,))
+    res = _u("g32/r", (M, N))
+    ad, wd = a.double(), w.double()
+    base = ad @ wd.t()
+    ac, wc, bc, rc = a.cuda(), w.cuda(), b.cuda(), res.cuda()
+    assert rel_err(gemm32(ac, wc), base) < 1e-5
+    assert rel_err(gemm32(ac, wc, bias=bc, act=1), F.gelu(base + b.double())) < 1e-5
+    assert rel_err(gemm32(ac, wc, bias=bc, act=3, residual=rc), F.relu6(base + b.double()) + res.double()) < 1e-5
+    assert rel_err(gemm32(ac, wc, act=6), F.relu(base)) < 1e-5
+    out = rc.clone()
+    gemm32(ac, wc, alpha=0.25, out=out, accumulate=True)
+    assert rel_err(out, res.double() + 0.25 * base) < 1e-5
+    if M % 4 == 0:                      # residual rows taken modulo (the abs-pos-embed add of the patch embedding)
+        want = base + res.double()[:M // 4].repeat(4, 1)
+        assert rel_err(gemm32(ac, wc, residual=rc[:M // 4], res_row_mod=M // 4), want) < 1e-5
+    big = torch.zeros(M, N + 12, device="cuda")                       # strided output view / strided operand view
+    gemm32(ac, wc, out=big[:, 4:4 + N])
+    assert rel_err(big[:, 4:4 + N], base) < 1e-5 and float(big[:, :4].abs().max()) == 0 and float(big[:, 4 + N:].abs().max()) == 0
+    if K >= 8:
+        assert rel_err(gemm32(ac[:, 4:], wc[:, 4:]), ad[:, 4:] @ wd[:, 4:].t()) < 1e-5
+
+
+def test_gemm_f32_rejects_bad_operands():
+    from ssrs_amd._lib import MfnetError
+    from ssrs_amd.fp32_path import gemm32
+    a, w = torch.zeros(8, 6, device="cuda"), torch.zeros(8, 6, device="cuda")
+    with pytest.raises(MfnetError):
+        gemm32(a, w)                     # K % 4
+    with pytest.raises(MfnetError):
+        gemm32(torch.zeros(8, 8), torch.zeros(8, 8))                # host tensors
+
+
+def _attn_ref(qkv, bias, rel_h, rel_w, G, S, heads, ws):
+    """oracle: pad the token map with rows equal to the qkv bias (what zero-padded tokens become), windows, attention."""
+    D3 = qkv.shape[-1]
+    x = qkv.view(G, S, S, D3)
+    if ws > 0:
+        pad = (ws - S % ws) % ws
+        Sp = S + pad
+        full = bias.view(1, 1, 1, D3).expand(G, Sp, Sp, D3).clone()
+        full[:, :S, :S] = x
+        win, pad_hw = R.window_partition(full, ws)
+        h = w = ws
+    else:
+        win, h, w = x, S, S
+    Bw = win.shape[0]
+    q, k, v = R.split_heads(win.reshape(Bw, h * w, D3), heads)
+    hd = D3 // (3 * heads)
+    o = R.merge_heads(R.attention_core(q, k, v, rel_h, rel_w, (h, w), hd ** -0.5), Bw, heads, h, w)
+    if ws > 0:
+        o = R.window_unpartition(o, ws, pad_hw, (S, S))
+    return o.reshape(G * S * S, -1)
+
+
+@pytest.mark.parametrize("S,ws,heads,hd", [(16, 14, 2, 64), (16, 0, 2, 64), (20, 14, 2, 80), (20, 0, 1, 80), (16, 14, 3, 32), (28, 14, 1, 64)])
+def test_attn_f32_vs_oracle(S, ws, heads, hd):
+    from ssrs_amd.fp32_path import attn32
+    G = 2
+    k = ws if ws else S
+    qkv = _u("a32/qkv", (G * S * S, 3 * heads * hd), 1.5)
+    bias = _u("a32/b", (3 * heads * hd,), 0.5)
+    rel_h, rel_w = _u("a32/rh", (2 * k - 1, hd)), _u("a32/rw", (2 * k - 1, hd))
+    ref = _attn_ref(qkv.double(), bias.double(), rel_h.double(), rel_w.double(), G, S, heads, ws)
+    out = attn32(qkv.cuda(), bias.cuda(), rel_h.cuda(), rel_w.cuda(), G, S, S, heads, ws, hd ** -0.5)
+    assert rel_err(out, ref) < 1e-5
+
+
+def _eval_case(tag, mod, encoder, batch):
+    from ssrs_amd.unetformer_mmsam import UNetFormer
+    g = golden(tag)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = UNetFormer(num_classes=6, encoder=encoder, args=_args(mod), precision="fp32")
+    m.load_state_dict(detfill.fill_state_dict(m.state_dict(), tag + "/"))
+    m = m.cuda().eval()
+    rgb, dsm, tgt = detfill.tiles(tag, batch, 256, 6)
+    out = m(rgb.cuda(), dsm.cuda())
+    assert out.shape == (batch, 6, 256, 256) and out.dtype == torch.float32
+    e = rel_err(out[:, :, ::4, ::4], g["eval_logits_s4"])
+    agree = float((out.argmax(1).cpu().numpy() == g["eval_argmax"]).mean())
+    csum = rel_err(out.double().sum((0, 2, 3)), g["eval_chan_sum"])
+    print(f"\n[{tag} fp32 path] logits rel err {e:.3e}  channel sums {csum:.3e}  argmax agreement {100 * agree:.4f} %")
+    assert e < FP32_TOL, e
+    assert csum < FP32_TOL, csum
+    assert agree >= 0.999, agree
+    return m, (rgb, dsm)
+
+
+@pytest.mark.parametrize("mod", ["sam_lora", "sam_adpt"])
+def test_tiny_model_fp32_logits_vs_reference(mod):
+    _eval_case(f"model_tiny_{mod}", mod, "vit_tiny_test", 2)
+
+
+@pytest.mark.parametrize("mod", ["sam_lora", "sam_adpt"])
+def test_vitb_fp32_logits_vs_reference(mod):
+    """BASELINE config (ViT-B, 256x256 tile): the 1e-4 bar of the fp32 path and the 99.9 % mask agreement."""
+    _eval_case(f"model_vitb_{mod}", mod, "vit_b", 1)
+
+
+def test_fp32_path_is_eval_only_and_switchable():
+    m, (rgb, dsm) = _eval_case("model_tiny_sam_lora", "sam_lora", "vit_tiny_test", 2)
+    with pytest.raises(NotImplementedError):
+        m.train()(rgb.cuda(), dsm.cuda())
+    m.eval()
+    m.precision = "bf16"                 # same module, same weights, the bf16 MFMA path: 2e-2 of the same golden
+    with torch.no_grad():
+        out = m(rgb.cuda(), dsm.cuda())
+    assert 1e-4 < rel_err(out[:, :, ::4, ::4], golden("model_tiny_sam_lora")["eval_logits_s4"]) < 2e-2
+    y3 = dsm[:, None].repeat(1, 3, 1, 1).cuda()                       # the 3-channel form of the second modality
+    m.precision = "fp32"
+    assert rel_err(m(rgb.cuda(), y3), m(rgb.cuda(), dsm.cuda())) < 1e-6
