@@ -17,6 +17,7 @@
 // indicator image staged beside K. T' is split hi + lo in bf16 (two k-steps), so the bias keeps fp32-level
 // accuracy, and it is pre-divided by `scale` so one multiply serves the whole logit.
 #include "attn_common.h"
+#include <mutex>
 #include <stdlib.h>
 
 struct AttnFwdParams {
@@ -236,8 +237,7 @@ static size_t attn_fwd_lds(const AttnGeom& g, int rowb) {
 
 // global attention whose key rows are exactly one 64-key tile wide: the separable-bias (ROWT) kernels apply
 bool attn_row_tiles(const AttnGeom& g) {
-  static const bool off = getenv("MFNET_ATTN_NO_ROWT") != nullptr;      // A/B aid: the general (indicator product) kernels
-  return !off && g.ws == 0 && g.KW == 64 && g.KH <= 64;
+  return g.ws == 0 && g.KW == 64 && g.KH <= 64;
 }
 
 // number of (window, 64-query tile) pairs of one image = grid.x of the query-tiled kernels
@@ -262,16 +262,24 @@ extern "C" int mfnet_attn_fwd(const void* qkv, const float* qkv_bias, const void
   p.qkv = (const bf16_t*)qkv; p.qkv_bias = qkv_bias; p.tbl = (const bf16_t*)tbl; p.out = (bf16_t*)out; p.lse = lse;
   const int rowb = hd <= 64 ? AttHd<64>::ROWB : AttHd<80>::ROWB;
   const size_t lds = attn_fwd_lds(p.g, rowb);
-  static bool attr_set = false;
-  if (!attr_set) {
-    const void* fns[8] = {(const void*)attn_fwd_kernel<1, 64, false>, (const void*)attn_fwd_kernel<2, 64, false>, (const void*)attn_fwd_kernel<4, 64, false>,
-                          (const void*)attn_fwd_kernel<1, 80, false>, (const void*)attn_fwd_kernel<2, 80, false>, (const void*)attn_fwd_kernel<4, 80, false>,
-                          (const void*)attn_fwd_kernel<4, 64, true>, (const void*)attn_fwd_kernel<4, 80, true>};
-    for (int i = 0; i < 8; ++i) {
-      hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) { mfnet_set_error("attn_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MFNET_ERR_HIP; }
+  // kernels that ask for more than 64 KB of dynamic LDS need the attribute once per device; the only state kept is the
+  // per-device "done" flag (guarded: entry points may be called from any thread)
+  {
+    static std::mutex mu;
+    static bool done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { mfnet_set_error("attn_fwd: hipGetDevice failed"); return MFNET_ERR_HIP; }
+    std::lock_guard<std::mutex> lk(mu);
+    if (!done[dev]) {
+      const void* fns[8] = {(const void*)attn_fwd_kernel<1, 64, false>, (const void*)attn_fwd_kernel<2, 64, false>, (const void*)attn_fwd_kernel<4, 64, false>,
+                            (const void*)attn_fwd_kernel<1, 80, false>, (const void*)attn_fwd_kernel<2, 80, false>, (const void*)attn_fwd_kernel<4, 80, false>,
+                            (const void*)attn_fwd_kernel<4, 64, true>, (const void*)attn_fwd_kernel<4, 80, true>};
+      for (int i = 0; i < 8; ++i) {
+        hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { mfnet_set_error("attn_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MFNET_ERR_HIP; }
+      }
+      done[dev] = true;
     }
-    attr_set = true;
   }
   MF_CHECK_ARG(p.g.KH + p.g.KW <= 128, "attn_fwd: key grid %dx%d too large (KH + KW <= 128)", p.g.KH, p.g.KW);
   dim3 grid((unsigned)attn_query_tiles(p.g), (unsigned)heads, (unsigned)G);

@@ -14,6 +14,7 @@
 //  * attn_bwd_dkv: one workgroup per 64 REAL keys (key on the lane), loops over the window's queries:
 //        dV^T += dO^T.P, dK^T += scale * Q^T.dS  with P / dS accumulator tiles reused as B operands.
 #include "attn_common.h"
+#include <mutex>
 #define F4Z make_float4(0.f, 0.f, 0.f, 0.f)
 
 struct AttnBwdParams {
@@ -511,19 +512,25 @@ extern "C" int mfnet_attn_bwd(const void* qkv, const float* qkv_bias, const void
   MF_CHECK_ARG(p.g.KH + p.g.KW <= 128, "attn_bwd: key grid %dx%d too large (KH + KW <= 128)", p.g.KH, p.g.KW);
   p.qkv = (const bf16_t*)qkv; p.qkv_bias = qkv_bias; p.tbl = (const bf16_t*)tbl; p.tblT = (const bf16_t*)tblT;
   p.out = (const bf16_t*)out; p.dout = (const bf16_t*)dout; p.lse = lse; p.dqkv = (bf16_t*)dqkv;
-  static bool attr_set = false;
-  if (!attr_set) {
-    const void* fns[16] = {(const void*)attn_bwd_dq_kernel<1, 64, false>, (const void*)attn_bwd_dq_kernel<2, 64, false>, (const void*)attn_bwd_dq_kernel<4, 64, false>,
-                           (const void*)attn_bwd_dkv_kernel<1, 64, false>, (const void*)attn_bwd_dkv_kernel<2, 64, false>, (const void*)attn_bwd_dkv_kernel<4, 64, false>,
-                           (const void*)attn_bwd_dq_kernel<1, 80, false>, (const void*)attn_bwd_dq_kernel<2, 80, false>, (const void*)attn_bwd_dq_kernel<4, 80, false>,
-                           (const void*)attn_bwd_dkv_kernel<1, 80, false>, (const void*)attn_bwd_dkv_kernel<2, 80, false>, (const void*)attn_bwd_dkv_kernel<4, 80, false>,
-                           (const void*)attn_bwd_dq_kernel<4, 64, true>, (const void*)attn_bwd_dkv_kernel<4, 64, true>,
-                           (const void*)attn_bwd_dq_kernel<4, 80, true>, (const void*)attn_bwd_dkv_kernel<4, 80, true>};
-    for (int i = 0; i < 16; ++i) {
-      hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) { mfnet_set_error("attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MFNET_ERR_HIP; }
+  {   // once per device, thread-safe (see attn.hip)
+    static std::mutex mu;
+    static bool done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { mfnet_set_error("attn_bwd: hipGetDevice failed"); return MFNET_ERR_HIP; }
+    std::lock_guard<std::mutex> lk(mu);
+    if (!done[dev]) {
+      const void* fns[16] = {(const void*)attn_bwd_dq_kernel<1, 64, false>, (const void*)attn_bwd_dq_kernel<2, 64, false>, (const void*)attn_bwd_dq_kernel<4, 64, false>,
+                             (const void*)attn_bwd_dkv_kernel<1, 64, false>, (const void*)attn_bwd_dkv_kernel<2, 64, false>, (const void*)attn_bwd_dkv_kernel<4, 64, false>,
+                             (const void*)attn_bwd_dq_kernel<1, 80, false>, (const void*)attn_bwd_dq_kernel<2, 80, false>, (const void*)attn_bwd_dq_kernel<4, 80, false>,
+                             (const void*)attn_bwd_dkv_kernel<1, 80, false>, (const void*)attn_bwd_dkv_kernel<2, 80, false>, (const void*)attn_bwd_dkv_kernel<4, 80, false>,
+                             (const void*)attn_bwd_dq_kernel<4, 64, true>, (const void*)attn_bwd_dkv_kernel<4, 64, true>,
+                             (const void*)attn_bwd_dq_kernel<4, 80, true>, (const void*)attn_bwd_dkv_kernel<4, 80, true>};
+      for (int i = 0; i < 16; ++i) {
+        hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { mfnet_set_error("attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MFNET_ERR_HIP; }
+      }
+      done[dev] = true;
     }
-    attr_set = true;
   }
   const int nsg = (p.g.KH + p.g.KW + 31) / 32;
   const int rowb = hd <= 64 ? AttHd<64>::ROWB : AttHd<80>::ROWB;

@@ -141,3 +141,24 @@ def test_fp32_path_is_eval_only_and_switchable():
     y3 = dsm[:, None].repeat(1, 3, 1, 1).cuda()                       # the 3-channel form of the second modality
     m.precision = "fp32"
     assert rel_err(m(rgb.cuda(), y3), m(rgb.cuda(), dsm.cuda())) < 1e-6
+
+
+def test_1024_tile_fp32_and_bf16_paths_agree():
+    """BASELINE configs[4] geometry (one 1024x1024 tile: 64x64 token grid, 25 windows of 14x14 with padding, global attention over
+    4096 keys) has no golden of the reference (its float64 run would take hours here); the two independent implementations
+    - fp32 kernels and bf16 MFMA kernels - must agree to the bf16 bound on it."""
+    from ssrs_amd.unetformer_mmsam import UNetFormer
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = UNetFormer(num_classes=6, encoder="vit_b", args=_args("sam_lora"))
+    m.load_state_dict(detfill.fill_state_dict(m.state_dict(), "model_vitb_sam_lora/"))
+    m = m.cuda().eval()
+    rgb, dsm, _ = detfill.tiles("t1024", 1, 1024, 6)
+    with torch.no_grad():
+        lo = m(rgb.cuda(), dsm.cuda())
+        m.precision = "fp32"
+        hi = m(rgb.cuda(), dsm.cuda())
+    e = rel_err(lo, hi)
+    agree = float((lo.argmax(1) == hi.argmax(1)).float().mean())
+    print(f"\n[vit_b 1024x1024] bf16 vs fp32 path: logits {e:.3e}, argmax agreement {100 * agree:.3f} %")
+    assert e < 2e-2 and agree > 0.98

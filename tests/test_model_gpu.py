@@ -243,7 +243,8 @@ def test_vitb_eval_logits_vs_reference():
 
 
 @pytest.mark.parametrize("mod,encoder,tile,batch", [("sam_adpt", "vit_b", 256, 2), ("sam_lora", "vit_b", 256, 2), ("sam_lora", "vit_l", 512, 1),
-                                                    ("sam_lora", "vit_h", 256, 1), ("sam_adpt", "vit_h", 256, 1)])
+                                                    ("sam_lora", "vit_h", 256, 1), ("sam_adpt", "vit_h", 256, 1),
+                                                    ("sam_lora", "vit_l", 1024, 1)])     # BASELINE configs[4]: whole 1024x1024 tile, 64x64 token grid
 def test_full_size_train_steps_run_and_learn(mod, encoder, tile, batch):
     """SURVEY 8(d) configurations at their real widths (768 / 1024 / 1280 channels, head dim 80 for ViT-H, adapters, a
     32x32 token grid with 9 windows for ViT-L at 512 px) through the graph-captured engine: every kernel accepts its shapes, the loss is finite
