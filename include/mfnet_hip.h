@@ -233,6 +233,12 @@ int mfnet_sgd_flat(float* p, const float* g, float* buf, int64_t n, float lr, fl
 int mfnet_tile_accumulate(float* pred, const float* logits, const int* coords, int64_t n, int64_t C, int64_t H,
                           int64_t W, int64_t h, int64_t w, int atomic, hipStream_t stream);
 int mfnet_argmax_chw(const float* pred, unsigned char* out, int64_t C, int64_t N, hipStream_t stream);
+/* float64-accumulator twins of the two above: the reference merges window logits in a float64 numpy array (evaluator.py:134,
+ * 169-176); sums of a few dozen fp32 logits are exact there, so the merged scores and the argmax mask do not depend on the
+ * order the (atomic) adds land in. src: fp32 logits (src_f64 = 0) or a float64 band from a neighbouring rank (src_f64 = 1). */
+int mfnet_tile_accumulate_f64(double* pred, const void* src, int src_f64, const int* coords, int64_t n, int64_t C, int64_t H,
+                              int64_t W, int64_t h, int64_t w, int atomic, hipStream_t stream);
+int mfnet_argmax_chw_f64(const double* pred, unsigned char* out, int64_t C, int64_t N, hipStream_t stream);
 int mfnet_minmax(const float* x, float* out, int64_t n, hipStream_t stream);
 int mfnet_scale_shift(const float* x, float* y, const float* mm, float unused, int64_t n, int mode, hipStream_t stream);
 

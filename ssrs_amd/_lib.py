@@ -52,6 +52,8 @@ _SIGS = {
     "mfnet_sgd_flat": [P, P, P, I64, F, F, F, F, P],
     "mfnet_tile_accumulate": [P, P, P, I64, I64, I64, I64, I64, I64, I, P],
     "mfnet_argmax_chw": [P, P, I64, I64, P],
+    "mfnet_tile_accumulate_f64": [P, P, I, P, I64, I64, I64, I64, I64, I64, I, P],
+    "mfnet_argmax_chw_f64": [P, P, I64, I64, P],
     "mfnet_minmax": [P, P, I64, P],
     "mfnet_scale_shift": [P, P, P, F, I64, I, P],
     "mfnet_adapter_mix": [P, P, P, P, P, P, I64, I64, P],

@@ -174,6 +174,54 @@ extern "C" int mfnet_argmax_chw(const float* pred, unsigned char* out, int64_t C
   return MFNET_OK;
 }
 
+// float64 accumulator twins: the reference merges window logits in a float64 numpy array in window order (evaluator.py:134,
+// 169-176). Sums of a few dozen fp32 values are exact in float64, so the order the atomics land in cannot change a bit:
+// the merged scores, and with them the argmax mask, are those of the reference for equal logits - and deterministic.
+// src is fp32 logits (src_f64 = 0) or a float64 band received from a neighbouring rank (src_f64 = 1).
+template <typename TSrc>
+__global__ __launch_bounds__(256) void tile_acc_f64_kernel(double* __restrict__ pred, const TSrc* __restrict__ src, const int* __restrict__ coords,
+                                                           int64_t n, int C, int64_t H, int64_t W, int h, int w, int atomic) {
+  const int64_t per = (int64_t)C * h * w, total = n * per;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / per;
+    int64_t r = i - t * per;
+    const int c = (int)(r / ((int64_t)h * w));
+    r -= (int64_t)c * h * w;
+    const int yy = (int)(r / w), xx = (int)(r - (int64_t)yy * w);
+    double* d = pred + ((int64_t)c * H + coords[2 * t] + yy) * W + coords[2 * t + 1] + xx;
+    const double v = (double)src[i];
+    if (atomic) atomicAdd(d, v); else *d += v;
+  }
+}
+extern "C" int mfnet_tile_accumulate_f64(double* pred, const void* src, int src_f64, const int* coords, int64_t n, int64_t C,
+                                         int64_t H, int64_t W, int64_t h, int64_t w, int atomic, hipStream_t stream) {
+  MF_CHECK_ARG(pred && src && coords && C > 0 && h > 0 && w > 0 && h <= H && w <= W, "tile_accumulate_f64: bad args");
+  if (n <= 0) return MFNET_OK;
+  const dim3 grid(grid_for(n * C * h * w));
+  if (src_f64) hipLaunchKernelGGL(tile_acc_f64_kernel<double>, grid, dim3(256), 0, stream, pred, (const double*)src, coords, n, (int)C, H, W, (int)h, (int)w, atomic);
+  else hipLaunchKernelGGL(tile_acc_f64_kernel<float>, grid, dim3(256), 0, stream, pred, (const float*)src, coords, n, (int)C, H, W, (int)h, (int)w, atomic);
+  MF_LAUNCH_CHECK("tile_accumulate_f64");
+  return MFNET_OK;
+}
+__global__ __launch_bounds__(256) void argmax_chw_f64_kernel(const double* __restrict__ pred, unsigned char* __restrict__ out, int C, int64_t N) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+    double mx = pred[i];
+    int am = 0;
+    for (int c = 1; c < C; ++c) {
+      const double v = pred[(int64_t)c * N + i];
+      if (v > mx) { mx = v; am = c; }
+    }
+    out[i] = (unsigned char)am;
+  }
+}
+extern "C" int mfnet_argmax_chw_f64(const double* pred, unsigned char* out, int64_t C, int64_t N, hipStream_t stream) {
+  MF_CHECK_ARG(pred && out && C > 0 && C < 256, "argmax_chw_f64: bad args");
+  if (N <= 0) return MFNET_OK;
+  hipLaunchKernelGGL(argmax_chw_f64_kernel, dim3(grid_for(N)), dim3(256), 0, stream, pred, out, (int)C, N);
+  MF_LAUNCH_CHECK("argmax_chw_f64");
+  return MFNET_OK;
+}
+
 // ----------------------------------------------------------------------------------- min-max normalise
 __device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }

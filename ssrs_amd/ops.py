@@ -482,21 +482,29 @@ def sgd_flat(p, g, buf, lr, momentum, wd, gscale=1.0):
 
 
 def tile_accumulate(pred, logits, coords, atomic=True):
-    """pred [C,H,W] fp32 += logits [n,C,h,w] placed at coords [n,2] int32 (row, col)."""
+    """pred [C,H,W] += logits [n,C,h,w] placed at coords [n,2] int32 (row, col). pred fp32 (logits fp32) or float64 (logits
+    fp32 or float64): the float64 accumulator is the reference's own (evaluator.py:134) - exact sums, order-independent."""
     _chk(pred, logits, coords)
     assert pred.is_contiguous() and logits.is_contiguous() and coords.dtype == torch.int32 and coords.is_contiguous()
     C, H, W = pred.shape
     n, C2, h, w = logits.shape
     assert C2 == C
+    if pred.dtype == torch.float64:
+        assert logits.dtype in (torch.float32, torch.float64)
+        call("mfnet_tile_accumulate_f64", pred.data_ptr(), logits.data_ptr(), 1 if logits.dtype == torch.float64 else 0, coords.data_ptr(),
+             n, C, H, W, h, w, 1 if atomic else 0, _stream(pred))
+        return
+    assert pred.dtype == torch.float32 and logits.dtype == torch.float32
     call("mfnet_tile_accumulate", pred.data_ptr(), logits.data_ptr(), coords.data_ptr(), n, C, H, W, h, w,
          1 if atomic else 0, _stream(pred))
 
 
 def argmax_chw(pred):
     _chk(pred)
+    assert pred.is_contiguous() and pred.dtype in (torch.float32, torch.float64)
     C = pred.shape[0]
     out = torch.empty(pred.shape[1:], dtype=torch.uint8, device=pred.device)
-    call("mfnet_argmax_chw", pred.data_ptr(), out.data_ptr(), C, out.numel(), _stream(pred))
+    call("mfnet_argmax_chw_f64" if pred.dtype == torch.float64 else "mfnet_argmax_chw", pred.data_ptr(), out.data_ptr(), C, out.numel(), _stream(pred))
     return out
 
 
