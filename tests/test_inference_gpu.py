@@ -76,6 +76,32 @@ def test_sliding_predict_with_model_vs_oracle():
     assert (mask.cpu().numpy() == ref_mask.numpy()).mean() > 0.98
 
 
+def test_graph_replayed_forward_is_bit_identical_to_eager():
+    """SlidingWindowPredictor / RasterInference with graph=True: the forward of each batch shape (full batches and the ragged
+    tail) is captured once into a HIP graph and replayed - same kernels, same order, so the rasters must be bit-identical."""
+    from ssrs_amd.inference import RasterInference, SlidingWindowPredictor
+    m = _tiny(2)
+    m.load_state_dict(detfill.fill_state_dict(m.state_dict(), "infer/"))
+    m = m.cuda().eval()
+    H, W = 600, 712
+    img = torch.from_numpy(0.5 * (detfill.uniform("graph/img", (3, H, W)) + 1)).float().cuda()
+    dsm = torch.from_numpy(20 + 5 * detfill.uniform("graph/dsm", (H, W))).float().cuda()
+    fwd = lambda a, b: m(a, b)                                  # noqa: E731
+    eager = SlidingWindowPredictor(fwd, 2, (256, 256), batch_size=8)
+    graph = SlidingWindowPredictor(fwd, 2, (256, 256), batch_size=8, graph=True)
+    me, (se, _) = eager.predict(img, dsm, 128, return_scores=True)
+    for _ in range(3):                                          # eager warm-up call, capturing call, replaying call
+        mg, (sg, _) = graph.predict(img, dsm, 128, return_scores=True)
+        assert torch.equal(sg, se) and torch.equal(mg, me)
+    assert len(graph.forward._graphs) == 2                      # 20 windows in batches of 8: shapes (8, ...) and (4, ...)
+    re_, rg = RasterInference(fwd, batch_size=8), RasterInference(fwd, batch_size=8, graph=True)
+    pe, qe = re_.predict(img, dsm)
+    for _ in range(3):
+        pg, qg = rg.predict(img, dsm)
+        # the blend sums overlapping tiles with fp32 atomics (order varies run to run): last-bit agreement, not bit equality
+        assert float((pg - pe).abs().max()) < 1e-6 and float((qg == qe).float().mean()) > 0.9999
+
+
 def test_raster_inference_blend_vs_numpy():
     """inference.py tile loop: window grid with shifted tail tiles, reflect padding of a short raster edge,
     per-tile DSM min-max, softmax class-1 probability; overlap blend = mean over covering tiles."""

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--encoder", default="vit_b")
     ap.add_argument("--mod", default="sam_lora")
     ap.add_argument("--skip-evaluator", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every forward eagerly instead of replaying a HIP graph per batch shape")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     a = ap.parse_args()
     from ssrs_amd import detfill
     from ssrs_amd.inference import RasterInference, SlidingWindowPredictor, get_sliding_windows, sliding_window
@@ -40,7 +42,7 @@ def main():
         args = argparse.Namespace(mod=a.mod, mid_dim=None, image_size=1024, multimask_output=1)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            m = UNetFormer(num_classes=ncls, encoder=a.encoder, args=args)
+            m = UNetFormer(num_classes=ncls, encoder=a.encoder, args=args, precision=a.precision)
         m.load_state_dict(detfill.fill_state_dict(m.state_dict(), "infer/"))
         m = m.to(dev).eval()
         g = torch.Generator(device="cpu").manual_seed(0)
@@ -48,17 +50,17 @@ def main():
         dsm = (torch.rand(a.size, a.size, generator=g) * 50.0).to(dev)
         fwd = lambda x, y: m(x, y)                           # noqa: E731
         if kind.startswith("inference"):
-            eng = RasterInference(fwd, batch_size=a.batch)
+            eng = RasterInference(fwd, batch_size=a.batch, graph=not a.no_graph)
             n = len(get_sliding_windows(a.size, a.size, (256, 256), eng.overlap))
             run = lambda: eng.predict(rgb, dsm)              # noqa: E731
-            warm = RasterInference(fwd, batch_size=a.batch)
-            small = (rgb[:, :1024, :1024].contiguous(), dsm[:1024, :1024].contiguous())
-            warm.predict(*small)
+            small = (rgb[:, :2048, :2048].contiguous(), dsm[:2048, :2048].contiguous())
+            eng.predict(*small)                                  # eager warm-up + graph capture of the full and the tail batch
         else:
-            eng = SlidingWindowPredictor(fwd, ncls, batch_size=a.batch)
+            eng = SlidingWindowPredictor(fwd, ncls, batch_size=a.batch, graph=not a.no_graph)
             img = rgb.float() / 255.0
             n = sum(1 for _ in sliding_window((a.size, a.size), 64, (256, 256)))
             run = lambda: eng.predict(img, dsm, 64)          # noqa: E731
+            eng.predict(img[:, :1024, :1024].contiguous(), dsm[:1024, :1024].contiguous(), 64)
             eng.predict(img[:, :1024, :1024].contiguous(), dsm[:1024, :1024].contiguous(), 64)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -83,7 +85,7 @@ def main():
         line = {"metric": "sliding-window inference window visits/sec", "grid": kind, "raster": f"{a.size}x{a.size}", "windows": n,
                 "value": round(n / dt, 1), "unit": "windows/s", "seconds_per_raster": round(dt, 3),
                 "pcie_inclusive_windows_per_s": round(n / dt_pcie, 1), "pcie_inclusive_seconds": round(dt_pcie, 3), "batch": a.batch,
-                "model": f"{a.encoder} {a.mod}, {ncls} classes", "dtype": "bf16", "data": "synthetic"}
+                "model": f"{a.encoder} {a.mod}, {ncls} classes", "dtype": a.precision, "hip_graph": not a.no_graph, "data": "synthetic"}
         print(json.dumps(line), flush=True)
         out.append(line)
         del m, eng
