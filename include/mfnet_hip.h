@@ -49,6 +49,13 @@ int mfnet_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, const float* ga
                         int64_t C, float eps, hipStream_t stream);
 /* dx = LN'(dy) (+ dres: the residual-stream gradient, fused), written as fp32 (dx) and/or bf16
  * (dx_bf16, ld = lddx); dgamma/dbeta [C] fp32 are ACCUMULATED into when non-null. */
+/* layernorm_fwd fused with the LoRA down-projection of the layer that consumes it (loralib/layers.py:157-158, 253, 261): y bf16,
+ * a_out[row, j] = sum_c y[row, c] * A[g][j, c] with A fp32 [n_groups][R][C] (group stride a_group_stride floats; n_groups = 2:
+ * the first rows/2 rows are modality x, the rest y), R in {4, 8}. With U != NULL (lora.Linear, n_groups = 2) also the
+ * cross-modal mix of layers.py:159-160: U [rows, 2R] = [wx*ax, (1-wx)*ay] for x rows, [(1-wy)*ax, wy*ay] for y rows. */
+int mfnet_layernorm_fwd_lora(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
+                             float* mean, float* rstd, int64_t rows, int64_t C, float eps, const float* A, int64_t a_group_stride,
+                             int n_groups, int R, float* a_out, const float* wx, const float* wy, float* U, hipStream_t stream);
 int mfnet_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, const void* x, int x_dtype, int64_t ldx,
                         const float* mean, const float* rstd, const float* gamma, const float* dres,
                         float* dx, void* dx_bf16, int64_t lddx, float* dgamma, float* dbeta, int64_t rows,

@@ -83,6 +83,137 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIn* __restrict__ x, 
   }
 }
 
+// LayerNorm forward fused with the LoRA down-projection of the layer that consumes it (loralib/layers.py:157-158, 253, 261):
+//   y = bf16(LN(x)),  a[row, j] = sum_c y[row, c] * bf16(A_g[j, c])   (A fp32 [G][R][C], g = the row's modality; the same
+//   bf16 x bf16 -> fp32 product skinny_nt forms)
+// and, for lora.Linear (MIX), the cross-modal mix of layers.py:159-160 on the spot:
+//   U[x row t] = [wx*ax[t], (1-wx)*ay[t]],  U[y row t] = [(1-wy)*ax[t], wy*ay[t]].
+// The wave already holds its whole row in registers, so the rank-R product is R*C/64 FMAs per lane and a halving
+// butterfly (R + log2(64) - 1 shuffles) instead of a second kernel that re-reads y (skinny_nt: 11.6 us per launch at
+// 8192 x 768) and a third one for the mix. A workgroup is 16 waves = 16 rows and stages A once in LDS as bf16 (a first
+// version read A from global per row: 24 KB per 3 KB row, 200 MB of L2 traffic per launch - as slow as the kernels it
+// replaced). With two groups a workgroup takes 8 token positions of BOTH modalities (wave 2p: x row, 2p+1: y row of
+// position 8b+p), so the mix needs only LDS.
+template <typename TIn, int R, bool MIX, int NVL>
+__global__ __launch_bounds__(1024) void ln_fwd_lora_kernel(const TIn* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, bf16_t* __restrict__ y, int64_t ldy,
+                                                           float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, int C, float eps,
+                                                           const float* __restrict__ A, int64_t half, int n_groups,
+                                                           float* __restrict__ a_out, const float* __restrict__ wx, const float* __restrict__ wy,
+                                                           float* __restrict__ U) {
+  extern __shared__ __align__(16) unsigned char ln_lds[];
+  bf16_t* Al = reinterpret_cast<bf16_t*>(ln_lds);                                 // [G][R][C] bf16
+  float* al = reinterpret_cast<float*>(ln_lds + (size_t)n_groups * R * C * 2);    // [8][2][R]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int g = 0;
+  int64_t row;
+  bool valid;
+  if (n_groups == 2) {
+    g = w & 1;
+    const int64_t t = 8 * (int64_t)blockIdx.x + (w >> 1);
+    valid = t < half;
+    row = g * half + t;
+  } else {
+    row = (int64_t)blockIdx.x * 16 + w;
+    valid = row < rows;
+  }
+  const int nv = C >> 2;
+  float4 v[NVL];
+  if (valid) {
+    const TIn* xr = x + row * ldx;
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+      const int c4 = lane + 64 * i;
+      if (c4 < nv) v[i] = ld4<TIn>(xr + 4 * c4);
+    }
+  }
+  {   // stage A (fp32 -> bf16) while the row loads are in flight
+    const int tot4 = n_groups * R * nv;
+    for (int i = threadIdx.x; i < tot4; i += 1024) {
+      const float4 t = *reinterpret_cast<const float4*>(A + 4 * (int64_t)i);
+      u32x2_t wv;
+      wv.x = pack_bf16x2(t.x, t.y);
+      wv.y = pack_bf16x2(t.z, t.w);
+      *reinterpret_cast<u32x2_t*>(Al + 4 * (int64_t)i) = wv;
+    }
+  }
+  float p[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) p[j] = 0.f;
+  float mu = 0.f, rs = 0.f;
+  if (valid) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NVL; ++i)
+      if (lane + 64 * i < nv) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NVL; ++i)
+      if (lane + 64 * i < nv) {
+        const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+        q += (a * a + b * b) + (c * c + d * d);
+      }
+    rs = rsqrtf(wave_sum(q) / (float)C + eps);
+    if (lane == 0) {
+      if (mean) mean[row] = mu;
+      if (rstd) rstd[row] = rs;
+    }
+  }
+  __syncthreads();                                             // A staged
+  if (valid) {
+    bf16_t* yr = y + row * ldy;
+    const bf16_t* Ag = Al + (size_t)g * R * C;
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+      const int c4 = lane + 64 * i;
+      if (c4 < nv) {
+        const float4 gm = *reinterpret_cast<const float4*>(gamma + 4 * c4);
+        const float4 bt = *reinterpret_cast<const float4*>(beta + 4 * c4);
+        u32x2_t wv;
+        wv.x = pack_bf16x2((v[i].x - mu) * rs * gm.x + bt.x, (v[i].y - mu) * rs * gm.y + bt.y);
+        wv.y = pack_bf16x2((v[i].z - mu) * rs * gm.z + bt.z, (v[i].w - mu) * rs * gm.w + bt.w);
+        *reinterpret_cast<u32x2_t*>(yr + 4 * c4) = wv;
+        const float o0 = bf16_lo(wv.x), o1 = bf16_hi(wv.x), o2 = bf16_lo(wv.y), o3 = bf16_hi(wv.y);     // what the GEMM will read
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const u32x2_t av = *reinterpret_cast<const u32x2_t*>(Ag + (size_t)j * C + 4 * c4);
+          p[j] = fmaf(o0, bf16_lo(av.x), fmaf(o1, bf16_hi(av.x), fmaf(o2, bf16_lo(av.y), fmaf(o3, bf16_hi(av.y), p[j]))));
+        }
+      }
+    }
+  }
+  // halving butterfly: after the step with offset `off` a lane keeps the half of its values selected by that lane bit
+  int jb = 0, off = 32;
+#pragma unroll
+  for (int n = R; n > 1; n >>= 1, off >>= 1) {
+    const bool up = (lane & off) != 0;
+#pragma unroll
+    for (int i = 0; i < n / 2; ++i) {
+      const float send = up ? p[i] : p[i + n / 2];
+      const float recv = __shfl_xor(send, off, 64);
+      p[i] = (up ? p[i + n / 2] : p[i]) + recv;
+    }
+    jb += up ? n / 2 : 0;
+  }
+  for (; off > 0; off >>= 1) p[0] += __shfl_xor(p[0], off, 64);
+  const bool writer = (lane & (64 / R - 1)) == 0;            // one lane per j
+  if (valid && writer) a_out[row * R + jb] = p[0];
+  if (MIX) {
+    if (writer) al[((w >> 1) * 2 + g) * R + jb] = p[0];
+    __syncthreads();
+    if (valid && lane < 2 * R) {
+      const float fx = wx[0], fy = wy[0];
+      const int jj = lane < R ? lane : lane - R;
+      const float ax = al[((w >> 1) * 2 + 0) * R + jj], ay = al[((w >> 1) * 2 + 1) * R + jj];
+      float u;
+      if (g == 0) u = lane < R ? fx * ax : (1.f - fx) * ay;
+      else u = lane < R ? (1.f - fy) * ax : fy * ay;
+      U[row * 2 * R + lane] = u;
+    }
+  }
+}
+
 // dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)) [+ dres]; optional bf16 copy of dx;
 // optional dgamma/dbeta accumulation (float atomics, one add per column per wave).
 // NVL = float4 chunks per lane (C <= 256 * NVL): the per-row register arrays are sized for the row at hand, which keeps
@@ -187,6 +318,51 @@ extern "C" int mfnet_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, cons
   else { mfnet_set_error("layernorm_fwd: bad dtype"); return MFNET_ERR_ARG; }
 #undef LN_FWD
   MF_LAUNCH_CHECK("layernorm_fwd");
+  return MFNET_OK;
+}
+
+extern "C" int mfnet_layernorm_fwd_lora(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
+                                        float* mean, float* rstd, int64_t rows, int64_t C, float eps, const float* A, int64_t a_group_stride,
+                                        int n_groups, int R, float* a_out, const float* wx, const float* wy, float* U, hipStream_t stream) {
+  MF_CHECK_ARG(x && y && gamma && beta && A && a_out, "layernorm_fwd_lora: null pointer");
+  MF_CHECK_ARG(rows >= 0 && C > 0 && C % 4 == 0 && C <= 64 * 4 * LN_MAXV, "layernorm_fwd_lora: C=%lld must be a multiple of 4 and <= %d",
+               (long long)C, 64 * 4 * LN_MAXV);
+  MF_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C, "layernorm_fwd_lora: bad leading dims");
+  MF_CHECK_ARG(R == 4 || R == 8, "layernorm_fwd_lora: R=%d (4 and 8 are built)", R);
+  MF_CHECK_ARG(n_groups == 1 || (n_groups == 2 && rows % 2 == 0 && a_group_stride == (int64_t)R * C),
+               "layernorm_fwd_lora: one group, or two contiguous groups [2][R][C] of rows/2 rows each");
+  MF_CHECK_ARG(!U || (wx && wy && n_groups == 2), "layernorm_fwd_lora: the cross-modal mix needs wx, wy and two groups");
+  MF_CHECK_ARG(((uintptr_t)A % 16) == 0, "layernorm_fwd_lora: A must be 16-byte aligned");
+  const size_t lds = (size_t)n_groups * R * C * 2 + 8 * 2 * R * sizeof(float);
+  MF_CHECK_ARG(lds <= 64 * 1024, "layernorm_fwd_lora: G*R*C = %lld does not fit the 64 KB LDS image", (long long)n_groups * R * C);
+  if (rows == 0) return MFNET_OK;
+  const int64_t half = rows / 2;
+  const int64_t nblk = n_groups == 2 ? ceil_div64(half, 8) : ceil_div64(rows, 16);
+  MF_CHECK_ARG(nblk < (1ll << 31), "layernorm_fwd_lora: too many rows");
+  dim3 grid((unsigned)nblk), block(1024);
+#define LN_LORA(TI, RR, MX, NV)                                                                                                \
+  hipLaunchKernelGGL((ln_fwd_lora_kernel<TI, RR, MX, NV>), grid, block, lds, stream, (const TI*)x, ldx, gamma, beta, (bf16_t*)y, ldy, mean, \
+                     rstd, rows, (int)C, eps, A, half, n_groups, a_out, wx, wy, U)
+#define LN_LORA_N(TI, RR, MX)                                   \
+  do {                                                          \
+    if (C <= 768) LN_LORA(TI, RR, MX, 3);                       \
+    else if (C <= 1280) LN_LORA(TI, RR, MX, 5);                 \
+    else LN_LORA(TI, RR, MX, LN_MAXV);                          \
+  } while (0)
+#define LN_LORA_T(TI)                                           \
+  do {                                                          \
+    if (R == 8 && U) LN_LORA_N(TI, 8, true);                    \
+    else if (R == 8) LN_LORA_N(TI, 8, false);                   \
+    else if (U) LN_LORA_N(TI, 4, true);                         \
+    else LN_LORA_N(TI, 4, false);                               \
+  } while (0)
+  if (x_dtype == MFNET_F32) LN_LORA_T(float);
+  else if (x_dtype == MFNET_BF16) LN_LORA_T(bf16_t);
+  else { mfnet_set_error("layernorm_fwd_lora: bad dtype"); return MFNET_ERR_ARG; }
+#undef LN_LORA_T
+#undef LN_LORA_N
+#undef LN_LORA
+  MF_LAUNCH_CHECK("layernorm_fwd_lora");
   return MFNET_OK;
 }
 

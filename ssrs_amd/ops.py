@@ -60,6 +60,23 @@ def layernorm_fwd(x, gamma, beta, eps, out_dtype=torch.bfloat16, want_stats=True
     return y, mean, rstd
 
 
+def layernorm_fwd_lora(x, gamma, beta, eps, A, wx=None, wy=None):
+    """LayerNorm -> bf16 plus the LoRA down-projection a = y @ A_g^T in the same launch. A fp32 [G, R, C] (G = 2: the first half
+    of the rows is modality x). With wx / wy also the mixed factor U [rows, 2R] of lora.Linear. -> (y, mean, rstd, a, U | None)."""
+    _chk(x, gamma, beta, A, wx, wy)
+    x2, rows, C, ldx = _rows2d(x)
+    assert A.dim() == 3 and A.is_contiguous() and A.dtype == torch.float32 and A.shape[2] == C
+    G, R = A.shape[0], A.shape[1]
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    a = torch.empty((rows, R), dtype=torch.float32, device=x.device)
+    U = torch.empty((rows, 2 * R), dtype=torch.float32, device=x.device) if wx is not None else None
+    call("mfnet_layernorm_fwd_lora", x2.data_ptr(), _DT[x.dtype], ldx, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), C, mean.data_ptr(),
+         rstd.data_ptr(), rows, C, float(eps), A.data_ptr(), R * C, G, R, a.data_ptr(), _p(wx), _p(wy), _p(U), _stream(x))
+    return y, mean, rstd, a, U
+
+
 def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, want_f32=True, want_bf16=False, dgamma=None, dbeta=None):
     """dx = LN'(dy) [+ dres]; returns (dx_f32 | None, dx_bf16 | None). dgamma/dbeta are accumulated into."""
     _chk(dy, x, mean, rstd, gamma, dres)

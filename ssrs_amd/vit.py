@@ -99,6 +99,11 @@ def _stack2(kind, a, b, transpose=False):
                    lambda t: [(t[0], a), (t[1], b)], device=a.device)
 
 
+def _ln_lora_fits(R, C):
+    """the fused LayerNorm + down-projection kernel keeps both modalities' A as bf16 in 64 KB of LDS"""
+    return 2 * R * C * 2 + 512 <= 65536
+
+
 def _down(x_bf, A_x, A_y, half):
     """a[m] = x[m] @ A_g^T with the modality-specific A (rows [0,half) -> A_x, rest -> A_y)."""
     return ops.skinny_nt(x_bf, _stack2("A", A_x, A_y), rows_per_group=half).contiguous()
@@ -157,8 +162,11 @@ class _LoraAttnBranch(torch.autograd.Function):
         half = M // 2
         r = Ax.shape[0] // 2
         h2 = h.reshape(M, D)
-        ln, mean, rstd = ops.layernorm_fwd(h2, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
-        a = _down(ln, Ax, Ay, half)
+        if 2 * r in (4, 8) and half % 2 == 0 and _ln_lora_fits(2 * r, D):      # LayerNorm and the down-projection a = LN(h) @ A_g^T in one launch
+            ln, mean, rstd, a, _ = ops.layernorm_fwd_lora(h2, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, _stack2("A", Ax, Ay))
+        else:
+            ln, mean, rstd = ops.layernorm_fwd(h2, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+            a = _down(ln, Ax, Ay, half)
         V = _qkv_lora_V(Bx, By, D, r)
         qkv = ops.gemm(ln, w_bf16(attn.qkv.weight), bias=attn.qkv.bias, U=a, V=V, rows_per_group=half,
                        n_groups=2, lr_scale=1.0 / r)
@@ -204,11 +212,15 @@ class _LoraAttnBranch(torch.autograd.Function):
         return (dh.view(dout.shape), None, None) + grads
 
 
-def _mix_linear_fwd(x_bf, lin, half, act, residual):
-    """lora.Linear forward on stacked rows: returns (out, pre|None, saved)."""
+def _mix_linear_fwd(x_bf, lin, half, act, residual, aU=None):
+    """lora.Linear forward on stacked rows: returns (out, pre|None, saved). aU: (a, U) if the producer of x_bf already made
+    them (ops.layernorm_fwd_lora)."""
     r = lin.lora_Ax.shape[0]
-    a = _down(x_bf, lin.lora_Ax, lin.lora_Ay, half)
-    U = ops.lora_mix_fwd(a, lin.lora_wx, lin.lora_wy)
+    if aU is not None:
+        a, U = aU
+    else:
+        a = _down(x_bf, lin.lora_Ax, lin.lora_Ay, half)
+        U = ops.lora_mix_fwd(a, lin.lora_wx, lin.lora_wy)
     V = _mix_V(lin)                                                # [N, 2r]
     if act:
         out, pre = ops.gemm(x_bf, w_bf16(lin.weight), bias=lin.bias, U=U, V=V, act=1, want_pre=True)
@@ -249,8 +261,15 @@ class _LoraMlpBranch(torch.autograd.Function):
         M = h.numel() // D
         half = M // 2
         h2 = h.reshape(M, D)
-        ln, mean, rstd = ops.layernorm_fwd(h2, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-        act, pre, s1 = _mix_linear_fwd(ln, blk.mlp.lin1, half, True, None)
+        l1 = blk.mlp.lin1
+        if l1.lora_Ax.shape[0] in (4, 8) and half % 2 == 0 and _ln_lora_fits(l1.lora_Ax.shape[0], D):     # LayerNorm, lin1's down-projection and its cross-modal mix in one launch
+            ln, mean, rstd, a1, U1 = ops.layernorm_fwd_lora(h2, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps,
+                                                            _stack2("A", l1.lora_Ax, l1.lora_Ay), l1.lora_wx.detach(), l1.lora_wy.detach())
+            aU = (a1, U1)
+        else:
+            ln, mean, rstd = ops.layernorm_fwd(h2, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+            aU = None
+        act, pre, s1 = _mix_linear_fwd(ln, l1, half, True, None, aU)
         out, _, s2 = _mix_linear_fwd(act, blk.mlp.lin2, half, False, h2)
         ctx.save_for_backward(h2, mean, rstd, ln, act, pre, *s1, *s2)
         ctx.blk = blk

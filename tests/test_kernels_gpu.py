@@ -54,6 +54,36 @@ def test_layernorm_fwd_bwd(ops, rows, C):
     assert rel_err(dx2, xd.grad) < 2e-5
 
 
+@pytest.mark.parametrize("rows,C,R,mix", [(512, 768, 8, False), (512, 768, 4, True), (36, 128, 4, True), (100, 1280, 8, False), (8192, 768, 4, True),
+                                          (64, 1024, 4, False)])
+def test_layernorm_fwd_with_lora_down_projection(ops, rows, C, R, mix):
+    """LayerNorm + a = y @ A_g^T (+ the cross-modal mix) in one launch == the three separate kernels' arithmetic: y and the
+    statistics bit-equal to layernorm_fwd, a / U against float64 products of the SAME bf16 y and bf16 A, and close to
+    what skinny_nt + lora_mix_fwd give."""
+    x = rnd(rows, C, seed=1, scale=3.0) + 0.5
+    g, b = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    A = 0.05 * rnd(2, R, C, seed=4)
+    wx, wy = torch.tensor([0.3], device="cuda"), torch.tensor([0.8], device="cuda")
+    y0, m0, r0 = ops.layernorm_fwd(x, g, b, 1e-6)
+    y, m, r, a, U = ops.layernorm_fwd_lora(x, g, b, 1e-6, A, wx if mix else None, wy if mix else None)
+    assert torch.equal(y, y0) and torch.equal(m, m0) and torch.equal(r, r0)
+    half = rows // 2
+    yd = y.double()
+    Ab = A.to(torch.bfloat16).double()                      # the kernel keeps A as bf16 in LDS, like skinny_nt's fragments
+    ax, ay = yd[:half] @ Ab[0].t(), yd[half:] @ Ab[1].t()
+    assert rel_err(a, torch.cat([ax, ay])) < 1e-5
+    if mix:
+        want = torch.cat([torch.cat([0.3 * ax, 0.7 * ay], 1), torch.cat([(1 - 0.8) * ax, 0.8 * ay], 1)])
+        assert rel_err(U, want) < 1e-5
+    else:
+        assert U is None
+    a_sep = ops.skinny_nt(y, A, rows_per_group=half) if half % 16 == 0 else None
+    if a_sep is not None:
+        assert rel_err(a, a_sep) < 1e-5
+    a1 = ops.layernorm_fwd_lora(x, g, b, 1e-6, A[:1].contiguous())[3]                 # one group: every row uses A[0]
+    assert rel_err(a1, yd @ Ab[0].t()) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(8192, 768, 768), (1024, 2304, 768), (512, 768, 3072), (800, 192, 768),
                                    (333, 256, 2304), (128, 128, 64), (5000, 3072, 768)])
