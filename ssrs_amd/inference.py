@@ -101,21 +101,48 @@ def plan_bands(rows: Sequence[int], heights: Sequence[int], H: int, world: int):
 
 
 def merge_bands(band: torch.Tensor, plan, rank: int, add_rows: Callable[[torch.Tensor, torch.Tensor], None], group=None):
-    """Chain exchange of the rows neighbouring bands share. band: [C, hi-lo, W] accumulator of `rank`.
-    add_rows(dst_rows_view_spec, src) adds a received [C, k, W] block onto the top k rows of the band."""
+    """Exchange of the rows neighbouring bands share. band: [C, hi-lo, W] accumulator of `rank`.
+    add_rows(band, src) adds a received [C, k, W] block onto the top k rows of the band. Every rank posts its send (its rows
+    below own_hi go to the next rank) and its receive (the previous rank's overhang) together, so the exchange is one
+    neighbour round trip whatever the world size - the rows a rank sends are not the rows it receives into (a blocking
+    receive-then-send made a chain whose latency grew with the number of ranks)."""
     world = len(plan)
     me = plan[rank]
+    # bands thinner than a window: a rank's overhang reaches past its neighbour's own rows and must be FORWARDED after it was
+    # received - only then is the exchange a chain (every rank sees the whole plan, so all take the same branch)
+    if any(plan[r - 1]["hi"] > plan[r]["own_hi"] for r in range(1, world - 1)):
+        if rank > 0:
+            prev = plan[rank - 1]
+            k = prev["hi"] - prev["own_hi"]
+            if k > 0:
+                buf = torch.empty((band.shape[0], k, band.shape[2]), dtype=band.dtype, device=band.device)
+                dist.recv(buf, src=dist.get_global_rank(group, rank - 1) if group is not None else rank - 1, group=group)
+                add_rows(band, buf)
+        if rank < world - 1:
+            k = me["hi"] - me["own_hi"]
+            if k > 0:
+                dist.send(band[:, me["own_hi"] - me["lo"]:me["hi"] - me["lo"], :].contiguous(),
+                          dst=dist.get_global_rank(group, rank + 1) if group is not None else rank + 1, group=group)
+        return
+    ops_, buf = [], None
+    if rank < world - 1:
+        k = me["hi"] - me["own_hi"]
+        if k > 0:
+            out = band[:, me["own_hi"] - me["lo"]:me["hi"] - me["lo"], :].contiguous()
+            dst = dist.get_global_rank(group, rank + 1) if group is not None else rank + 1
+            ops_.append(dist.P2POp(dist.isend, out, dst, group))
     if rank > 0:
         prev = plan[rank - 1]
         k = prev["hi"] - prev["own_hi"]
         if k > 0:
             buf = torch.empty((band.shape[0], k, band.shape[2]), dtype=band.dtype, device=band.device)
-            dist.recv(buf, src=rank - 1, group=group)
-            add_rows(band, buf)
-    if rank < world - 1:
-        k = me["hi"] - me["own_hi"]
-        if k > 0:
-            dist.send(band[:, me["own_hi"] - me["lo"]:me["hi"] - me["lo"], :].contiguous(), dst=rank + 1, group=group)
+            src = dist.get_global_rank(group, rank - 1) if group is not None else rank - 1
+            ops_.append(dist.P2POp(dist.irecv, buf, src, group))
+    if ops_:
+        for req in dist.batch_isend_irecv(ops_):
+            req.wait()
+    if buf is not None:
+        add_rows(band, buf)
 
 
 def _coords4(tuples, H, W, h, w, device):

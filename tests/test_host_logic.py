@@ -78,9 +78,9 @@ def _init(rank, world, port):
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
 
-def _merge_worker(rank, world, port, q):
+def _merge_worker(rank, world, port, q, cfg=(600, 700, 64, 256)):
     _init(rank, world, port)
-    H, W, stride, win = 600, 700, 64, 256
+    H, W, stride, win = cfg
     coords, tiles, full, plan, bands = _simulate(H, W, stride, win, world)
     band = torch.from_numpy(bands[rank]).clone()
 
@@ -108,6 +108,17 @@ def _run(fn, world, port):
 
 def test_band_merge_two_processes_gloo():
     for rank, err in _run(_merge_worker, 2, 29611):
+        assert err < 1e-12, (rank, err)
+
+
+@pytest.mark.parametrize("world,cfg,port", [(4, (1536, 320, 128, 256), 29621),    # every rank posts send + receive at once
+                                            (4, (600, 700, 64, 256), 29622)])     # bands thinner than a window: forwarding chain
+def test_band_merge_more_ranks_gloo(world, cfg, port):
+    import functools
+    plan = _simulate(*cfg, world)[3]
+    chain = any(plan[r - 1]["hi"] > plan[r]["own_hi"] for r in range(1, len(plan) - 1))
+    assert chain == (cfg[0] == 600)                                                # the two cases take the two branches
+    for rank, err in _run(functools.partial(_merge_worker, cfg=cfg), world, port):
         assert err < 1e-12, (rank, err)
 
 
