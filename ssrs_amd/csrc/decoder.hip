@@ -764,9 +764,12 @@ __device__ __forceinline__ void gla_ld8(const float* p, float* o) {          // 
 template <typename T>
 __global__ __launch_bounds__(256) void gla_attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ table,
                                                            float* __restrict__ out, const GlaParams p) {
-  __shared__ float kl[4][64][GLA_HD + 1], vl[4][64][GLA_HD + 1];
+  __shared__ float4 kl[4][64][2], vl[4][64][2];      // rows as two float4: broadcast ds_read_b128 in the key loops
+  __shared__ float tl[4][GLA_NB];             // this head's bias column: the inner loops gather from LDS, not from global memory
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int head = blockIdx.y * 4 + wv;
+  if (head < p.heads)
+    for (int i = lane; i < GLA_NB; i += 64) tl[wv][i] = table[i * p.heads + head];
   const int nww = p.W / GLA_WS, nwh = p.H / GLA_WS;
   const int win = blockIdx.x;
   const int b = win / (nwh * nww), wy = (win / nww) % nwh, wx = win % nww;
@@ -779,8 +782,8 @@ __global__ __launch_bounds__(256) void gla_attn_fwd_kernel(const T* __restrict__
     gla_ld8(qkv + row * Cq + head * GLA_HD, q);
     gla_ld8(qkv + row * Cq + (p.heads + head) * GLA_HD, k);
     gla_ld8(qkv + row * Cq + (2 * p.heads + head) * GLA_HD, v);
-#pragma unroll
-    for (int d = 0; d < 8; ++d) { kl[wv][lane][d] = k[d]; vl[wv][lane][d] = v[d]; }
+    kl[wv][lane][0] = make_float4(k[0], k[1], k[2], k[3]); kl[wv][lane][1] = make_float4(k[4], k[5], k[6], k[7]);
+    vl[wv][lane][0] = make_float4(v[0], v[1], v[2], v[3]); vl[wv][lane][1] = make_float4(v[4], v[5], v[6], v[7]);
   }
   __syncthreads();
   if (!on) return;
@@ -788,11 +791,10 @@ __global__ __launch_bounds__(256) void gla_attn_fwd_kernel(const T* __restrict__
   float mx = -FLT_MAX;
 #pragma unroll
   for (int j = 0; j < 64; ++j) {
-    float a = 0.f;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) a = fmaf(q[d], kl[wv][j][d], a);
+    const float4 k0 = kl[wv][j][0], k1 = kl[wv][j][1];
+    float a = fmaf(q[0], k0.x, fmaf(q[1], k0.y, fmaf(q[2], k0.z, fmaf(q[3], k0.w, fmaf(q[4], k1.x, fmaf(q[5], k1.y, fmaf(q[6], k1.z, q[7] * k1.w)))))));
     const int idx = (ty - (j >> 3) + GLA_WS - 1) * (2 * GLA_WS - 1) + (tx - (j & 7) + GLA_WS - 1);
-    a = a * p.scale + table[idx * p.heads + head];
+    a = a * p.scale + tl[wv][idx];
     s[j] = a;
     mx = fmaxf(mx, a);
   }
@@ -801,112 +803,161 @@ __global__ __launch_bounds__(256) void gla_attn_fwd_kernel(const T* __restrict__
   for (int j = 0; j < 64; ++j) {
     const float e = __expf(s[j] - mx);
     l += e;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) o[d] = fmaf(e, vl[wv][j][d], o[d]);
+    const float4 v0 = vl[wv][j][0], v1 = vl[wv][j][1];
+    o[0] = fmaf(e, v0.x, o[0]); o[1] = fmaf(e, v0.y, o[1]); o[2] = fmaf(e, v0.z, o[2]); o[3] = fmaf(e, v0.w, o[3]);
+    o[4] = fmaf(e, v1.x, o[4]); o[5] = fmaf(e, v1.y, o[5]); o[6] = fmaf(e, v1.z, o[6]); o[7] = fmaf(e, v1.w, o[7]);
   }
   const float inv = 1.f / l;
   float* op = out + row * (p.heads * GLA_HD) + head * GLA_HD;
   reinterpret_cast<float4*>(op)[0] = make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
   reinterpret_cast<float4*>(op)[1] = make_float4(o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv);
 }
-// backward: pass 1 (lane = query) -> max, sum, delta, dq, table-gradient adds; pass 2 (lane = key) -> dk, dv.
-// dtable [225, heads] is ADDED into: a block loops over several windows and keeps its share in LDS.
+// backward: pass 1 (lane = query) -> max, sum, delta (one online-softmax sweep), then dq and the table-gradient adds (second
+// sweep); pass 2 (lane = key) -> dk, dv. dtable [225, heads] is ADDED into: a block loops over several windows and keeps its
+// share in LDS. K / V / Q / dO rows sit in LDS as two float4 each and are read as broadcasts (all lanes the same row): four
+// ds_read_b128 per key instead of sixteen ds_read_b32 - the kernel is a chain of LDS reads, not of arithmetic.
+struct GlaRow { float4 lo, hi; };
+__device__ __forceinline__ float gla_dot8(const float* a, const GlaRow& r) {
+  return fmaf(a[0], r.lo.x, fmaf(a[1], r.lo.y, fmaf(a[2], r.lo.z, fmaf(a[3], r.lo.w,
+         fmaf(a[4], r.hi.x, fmaf(a[5], r.hi.y, fmaf(a[6], r.hi.z, a[7] * r.hi.w)))))));
+}
+__device__ __forceinline__ void gla_axpy8(float* acc, float s, const GlaRow& r) {
+  acc[0] = fmaf(s, r.lo.x, acc[0]); acc[1] = fmaf(s, r.lo.y, acc[1]); acc[2] = fmaf(s, r.lo.z, acc[2]); acc[3] = fmaf(s, r.lo.w, acc[3]);
+  acc[4] = fmaf(s, r.hi.x, acc[4]); acc[5] = fmaf(s, r.hi.y, acc[5]); acc[6] = fmaf(s, r.hi.z, acc[6]); acc[7] = fmaf(s, r.hi.w, acc[7]);
+}
+__device__ __forceinline__ GlaRow gla_row(const float* v) {
+  GlaRow r;
+  r.lo = make_float4(v[0], v[1], v[2], v[3]);
+  r.hi = make_float4(v[4], v[5], v[6], v[7]);
+  return r;
+}
+// One workgroup = one (window, head); its four waves split the 64 keys (pass 1) / the 64 queries (pass 2) and meet in LDS.
+// (One wave per (window, head) executed ~10 k dependent wave64 VALU instructions back to back: 45-120 us per launch whatever
+// the map size.)
 __global__ __launch_bounds__(256) void gla_attn_bwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ table,
                                                            const float* __restrict__ dout, bf16_t* __restrict__ dqkv,
                                                            float* __restrict__ dtable, const GlaParams p, int nwin) {
-  __shared__ float ql[4][64][GLA_HD + 1], kl[4][64][GLA_HD + 1], vl[4][64][GLA_HD + 1], dol[4][64][GLA_HD + 1];
-  __shared__ float ml[4][64], ll[4][64], dl[4][64];
-  __shared__ float dtl[4][GLA_NB];
+  __shared__ GlaRow ql[64], kl[64], vl[64], dol[64];
+  __shared__ float pm[4][64], pl[4][64], pd[4][64];             // per-wave partial max / sum / delta sum of each query
+  __shared__ float ml[64], ll[64], dl[64];
+  __shared__ float part[4][64][17];                             // per-wave partial dq (8) or dk | dv (16) of each token
+  __shared__ float dtl[GLA_NB], tl[GLA_NB];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int head = blockIdx.y * 4 + wv;
-  const bool on = head < p.heads;
+  const int head = blockIdx.y;
+  for (int i = threadIdx.x; i < GLA_NB; i += 256) { tl[i] = table[i * p.heads + head]; dtl[i] = 0.f; }
   const int nww = p.W / GLA_WS, nwh = p.H / GLA_WS;
   const int ty = lane >> 3, tx = lane & 7;
   const int Cq = 3 * p.heads * GLA_HD, Co = p.heads * GLA_HD;
-  for (int i = lane; i < GLA_NB; i += 64) dtl[wv][i] = 0.f;
+  const int ib = (ty + GLA_WS - 1) * (2 * GLA_WS - 1) + (tx + GLA_WS - 1);       // bias index of (this lane as query, key 0)
+  const int kb = (GLA_WS - 1 - ty) * (2 * GLA_WS - 1) + (GLA_WS - 1 - tx);       // bias index of (query 0, this lane as key)
+  const int j0 = 16 * wv;
   for (int win = blockIdx.x; win < nwin; win += gridDim.x) {
     const int b = win / (nwh * nww), wy = (win / nww) % nwh, wx = win % nww;
     const int64_t row = ((int64_t)b * p.H + wy * GLA_WS + ty) * p.W + wx * GLA_WS + tx;
-    float q[8], k[8], v[8], dO[8];
     __syncthreads();                      // previous window's LDS fully consumed
-    if (on) {
-      gla_ld8(qkv + row * Cq + head * GLA_HD, q);
-      gla_ld8(qkv + row * Cq + (p.heads + head) * GLA_HD, k);
-      gla_ld8(qkv + row * Cq + (2 * p.heads + head) * GLA_HD, v);
-      const float4 d0 = reinterpret_cast<const float4*>(dout + row * Co + head * GLA_HD)[0];
-      const float4 d1 = reinterpret_cast<const float4*>(dout + row * Co + head * GLA_HD)[1];
-      dO[0] = d0.x; dO[1] = d0.y; dO[2] = d0.z; dO[3] = d0.w; dO[4] = d1.x; dO[5] = d1.y; dO[6] = d1.z; dO[7] = d1.w;
-#pragma unroll
-      for (int d = 0; d < 8; ++d) { ql[wv][lane][d] = q[d]; kl[wv][lane][d] = k[d]; vl[wv][lane][d] = v[d]; dol[wv][lane][d] = dO[d]; }
+    {
+      float t[8];
+      if (wv < 3) {
+        gla_ld8(qkv + row * Cq + (wv * p.heads + head) * GLA_HD, t);
+      } else {
+        const float4 d0 = reinterpret_cast<const float4*>(dout + row * Co + head * GLA_HD)[0];
+        const float4 d1 = reinterpret_cast<const float4*>(dout + row * Co + head * GLA_HD)[1];
+        t[0] = d0.x; t[1] = d0.y; t[2] = d0.z; t[3] = d0.w; t[4] = d1.x; t[5] = d1.y; t[6] = d1.z; t[7] = d1.w;
+      }
+      (wv == 0 ? ql : wv == 1 ? kl : wv == 2 ? vl : dol)[lane] = gla_row(t);
     }
     __syncthreads();
-    if (on) {
-      // ---- pass 1: this lane's query. Three sweeps over the keys that recompute the 8-wide dot
-      // products instead of holding 64 scores in registers (the first version spilled).
-      float mx = -FLT_MAX;
-#pragma unroll 4
-      for (int j = 0; j < 64; ++j) {
-        float a = 0.f;
+    float q[8], dO[8];
+    {
+      const GlaRow a = ql[lane], c = dol[lane];
+      q[0] = a.lo.x; q[1] = a.lo.y; q[2] = a.lo.z; q[3] = a.lo.w; q[4] = a.hi.x; q[5] = a.hi.y; q[6] = a.hi.z; q[7] = a.hi.w;
+      dO[0] = c.lo.x; dO[1] = c.lo.y; dO[2] = c.lo.z; dO[3] = c.lo.w; dO[4] = c.hi.x; dO[5] = c.hi.y; dO[6] = c.hi.z; dO[7] = c.hi.w;
+    }
+    // ---- pass 1a: this lane's query against this wave's 16 keys: scores kept, partial max / sum / delta sum
+    float sc[16], dpv[16];
+    float mx = -FLT_MAX;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) a = fmaf(q[d], kl[wv][j][d], a);
-        const int idx = (ty - (j >> 3) + GLA_WS - 1) * (2 * GLA_WS - 1) + (tx - (j & 7) + GLA_WS - 1);
-        mx = fmaxf(mx, a * p.scale + table[idx * p.heads + head]);
-      }
-      float l = 0.f, delta = 0.f;
-#pragma unroll 4
-      for (int j = 0; j < 64; ++j) {
-        float a = 0.f, dp = 0.f;
+    for (int jj = 0; jj < 16; ++jj) {
+      const int j = j0 + jj;
+      const int idx = ib - (j >> 3) * (2 * GLA_WS - 1) - (j & 7);
+      sc[jj] = gla_dot8(q, kl[j]) * p.scale + tl[idx];
+      dpv[jj] = gla_dot8(dO, vl[j]);
+      mx = fmaxf(mx, sc[jj]);
+    }
+    float l = 0.f, dsum = 0.f;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) { a = fmaf(q[d], kl[wv][j][d], a); dp = fmaf(dO[d], vl[wv][j][d], dp); }
-        const int idx = (ty - (j >> 3) + GLA_WS - 1) * (2 * GLA_WS - 1) + (tx - (j & 7) + GLA_WS - 1);
-        const float e = __expf(a * p.scale + table[idx * p.heads + head] - mx);
-        l += e;
-        delta = fmaf(e, dp, delta);
-      }
-      const float inv = 1.f / l;
-      delta *= inv;
-      float dq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 4
-      for (int j = 0; j < 64; ++j) {
-        float a = 0.f, dp = 0.f;
+    for (int jj = 0; jj < 16; ++jj) {
+      const float e = __expf(sc[jj] - mx);
+      l += e;
+      dsum = fmaf(e, dpv[jj], dsum);
+    }
+    pm[wv][lane] = mx; pl[wv][lane] = l; pd[wv][lane] = dsum;
+    __syncthreads();
+    float M = fmaxf(fmaxf(pm[0][lane], pm[1][lane]), fmaxf(pm[2][lane], pm[3][lane]));
+    float L = 0.f, Dm = 0.f;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) { a = fmaf(q[d], kl[wv][j][d], a); dp = fmaf(dO[d], vl[wv][j][d], dp); }
-        const int idx = (ty - (j >> 3) + GLA_WS - 1) * (2 * GLA_WS - 1) + (tx - (j & 7) + GLA_WS - 1);
-        const float ds = __expf(a * p.scale + table[idx * p.heads + head] - mx) * inv * (dp - delta);
-        atomicAdd(&dtl[wv][idx], ds);        // distinct idx per lane for a fixed j
+    for (int w = 0; w < 4; ++w) {
+      const float c = __expf(pm[w][lane] - M);
+      L = fmaf(pl[w][lane], c, L);
+      Dm = fmaf(pd[w][lane], c, Dm);
+    }
+    const float inv = 1.f / L, delta = Dm * inv;
+    if (wv == 0) { ml[lane] = M; ll[lane] = inv; dl[lane] = delta; }
+    // ---- pass 1b: partial dq over this wave's keys, table-gradient adds
+    float dq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int d = 0; d < 8; ++d) dq[d] = fmaf(ds * p.scale, kl[wv][j][d], dq[d]);
-      }
-      ml[wv][lane] = mx; ll[wv][lane] = inv; dl[wv][lane] = delta;
+    for (int jj = 0; jj < 16; ++jj) {
+      const int j = j0 + jj;
+      const int idx = ib - (j >> 3) * (2 * GLA_WS - 1) - (j & 7);
+      const float ds = __expf(sc[jj] - M) * inv * (dpv[jj] - delta);
+      atomicAdd(&dtl[idx], ds);
+      gla_axpy8(dq, ds * p.scale, kl[j]);
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) part[wv][lane][d] = dq[d];
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int d = 0; d < 8; ++d) dq[d] = (part[0][lane][d] + part[1][lane][d]) + (part[2][lane][d] + part[3][lane][d]);
       u32x4_t w;
       w.x = pack_bf16x2(dq[0], dq[1]); w.y = pack_bf16x2(dq[2], dq[3]); w.z = pack_bf16x2(dq[4], dq[5]); w.w = pack_bf16x2(dq[6], dq[7]);
       *reinterpret_cast<u32x4_t*>(dqkv + row * Cq + head * GLA_HD) = w;
     }
+    __syncthreads();                      // ml / ll / dl visible, part[] free again
+    // ---- pass 2: this lane's key / value against this wave's 16 queries
+    float k[8], v[8];
+    {
+      const GlaRow a = kl[lane], c = vl[lane];
+      k[0] = a.lo.x; k[1] = a.lo.y; k[2] = a.lo.z; k[3] = a.lo.w; k[4] = a.hi.x; k[5] = a.hi.y; k[6] = a.hi.z; k[7] = a.hi.w;
+      v[0] = c.lo.x; v[1] = c.lo.y; v[2] = c.lo.z; v[3] = c.lo.w; v[4] = c.hi.x; v[5] = c.hi.y; v[6] = c.hi.z; v[7] = c.hi.w;
+    }
+    float dk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ii = 0; ii < 16; ++ii) {
+      const int i = j0 + ii;
+      const GlaRow qr = ql[i], dr = dol[i];
+      const int idx = kb + (i >> 3) * (2 * GLA_WS - 1) + (i & 7);
+      const float a = gla_dot8(k, qr) * p.scale + tl[idx];
+      const float dp = gla_dot8(v, dr);
+      const float pr = __expf(a - ml[i]) * ll[i];
+      const float ds = pr * (dp - dl[i]) * p.scale;
+      gla_axpy8(dk, ds, qr);
+      gla_axpy8(dv, pr, dr);
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { part[wv][lane][d] = dk[d]; part[wv][lane][8 + d] = dv[d]; }
     __syncthreads();
-    if (on) {
-      // ---- pass 2: this lane's key / value
-      float dk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 4
-      for (int i = 0; i < 64; ++i) {
-        float a = 0.f, dp = 0.f;
+    if (wv < 2) {                          // wave 0 sums and stores dk, wave 1 dv
+      float r[8];
 #pragma unroll
-        for (int d = 0; d < 8; ++d) { a = fmaf(ql[wv][i][d], k[d], a); dp = fmaf(dol[wv][i][d], v[d], dp); }
-        const int idx = ((i >> 3) - ty + GLA_WS - 1) * (2 * GLA_WS - 1) + ((i & 7) - tx + GLA_WS - 1);
-        a = a * p.scale + table[idx * p.heads + head];
-        const float pr = __expf(a - ml[wv][i]) * ll[wv][i];
-        const float ds = pr * (dp - dl[wv][i]) * p.scale;
-#pragma unroll
-        for (int d = 0; d < 8; ++d) { dk[d] = fmaf(ds, ql[wv][i][d], dk[d]); dv[d] = fmaf(pr, dol[wv][i][d], dv[d]); }
-      }
+      for (int d = 0; d < 8; ++d) r[d] = (part[0][lane][8 * wv + d] + part[1][lane][8 * wv + d]) + (part[2][lane][8 * wv + d] + part[3][lane][8 * wv + d]);
       u32x4_t w;
-      w.x = pack_bf16x2(dk[0], dk[1]); w.y = pack_bf16x2(dk[2], dk[3]); w.z = pack_bf16x2(dk[4], dk[5]); w.w = pack_bf16x2(dk[6], dk[7]);
-      *reinterpret_cast<u32x4_t*>(dqkv + row * Cq + (p.heads + head) * GLA_HD) = w;
-      w.x = pack_bf16x2(dv[0], dv[1]); w.y = pack_bf16x2(dv[2], dv[3]); w.z = pack_bf16x2(dv[4], dv[5]); w.w = pack_bf16x2(dv[6], dv[7]);
-      *reinterpret_cast<u32x4_t*>(dqkv + row * Cq + (2 * p.heads + head) * GLA_HD) = w;
+      w.x = pack_bf16x2(r[0], r[1]); w.y = pack_bf16x2(r[2], r[3]); w.z = pack_bf16x2(r[4], r[5]); w.w = pack_bf16x2(r[6], r[7]);
+      *reinterpret_cast<u32x4_t*>(dqkv + row * Cq + ((1 + wv) * p.heads + head) * GLA_HD) = w;
     }
   }
   __syncthreads();
-  if (on) for (int i = lane; i < GLA_NB; i += 64) atomicAdd(dtable + i * p.heads + head, dtl[wv][i]);
+  for (int i = threadIdx.x; i < GLA_NB; i += 256) atomicAdd(dtable + i * p.heads + head, dtl[i]);
 }
 static int gla_check(GlaParams* p, int64_t B, int64_t H, int64_t W, int64_t heads, int64_t hd, int64_t ws, float scale, const char* who) {
   MF_CHECK_ARG(hd == GLA_HD && ws == GLA_WS, "%s: only head dim 8 / window 8 (decode_channels 64, 8 heads) are implemented", who);
@@ -946,7 +997,7 @@ extern "C" int mfnet_gla_attn_bwd(const void* qkv, const float* table, const flo
   if (rc) return rc;
   const int64_t nwin = B * (H / GLA_WS) * (W / GLA_WS);
   const unsigned gx = (unsigned)(nwin < 512 ? nwin : 512);
-  hipLaunchKernelGGL(gla_attn_bwd_kernel, dim3(gx, (unsigned)ceil_div64(heads, 4)), dim3(256), 0, stream, (const bf16_t*)qkv, table, dout,
+  hipLaunchKernelGGL(gla_attn_bwd_kernel, dim3(gx, (unsigned)heads), dim3(256), 0, stream, (const bf16_t*)qkv, table, dout,
                      (bf16_t*)dqkv, dtable, p, (int)nwin);
   MF_LAUNCH_CHECK("gla_attn_bwd");
   return MFNET_OK;
