@@ -56,6 +56,10 @@ int mfnet_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, const float* ga
 int mfnet_layernorm_fwd_lora(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
                              float* mean, float* rstd, int64_t rows, int64_t C, float eps, const float* A, int64_t a_group_stride,
                              int n_groups, int R, float* a_out, const float* wx, const float* wy, float* U, hipStream_t stream);
+/* the same down-projection (+ mix) for a layer whose input is not a LayerNorm output (lin2 reads GELU(lin1)): x bf16 [rows, C],
+ * C % 8 == 0, C <= 4096; replaces mfnet_skinny_nt + mfnet_lora_mix_fwd on that path. */
+int mfnet_lora_down_mix(const void* x, int64_t ldx, int64_t rows, int64_t C, const float* A, int64_t a_group_stride, int n_groups, int R,
+                        float* a_out, const float* wx, const float* wy, float* U, hipStream_t stream);
 int mfnet_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, const void* x, int x_dtype, int64_t ldx,
                         const float* mean, const float* rstd, const float* gamma, const float* dres,
                         float* dx, void* dx_bf16, int64_t lddx, float* dgamma, float* dbeta, int64_t rows,

@@ -31,6 +31,7 @@ P, I64, I, F, D = c_void_p, c_int64, c_int, c_float, c_double
 _SIGS = {
     "mfnet_layernorm_fwd": [P, I, I64, P, P, P, I, I64, P, P, I64, I64, F, P],
     "mfnet_layernorm_fwd_lora": [P, I, I64, P, P, P, I64, P, P, I64, I64, F, P, I64, I, I, P, P, P, P, P],
+    "mfnet_lora_down_mix": [P, I64, I64, I64, P, I64, I, I, P, P, P, P, P],
     "mfnet_layernorm_bwd": [P, I, I64, P, I, I64, P, P, P, P, P, P, I64, P, P, I64, I64, P],
     "mfnet_gemm_bf16": [P, I64, P, I64, I64, I64, I64, P, P, I64, P, I64, I64, I, I, F, I, P, I64, P, I64,
                         P, I64, I64, P, I, I64, I, P],

@@ -214,6 +214,101 @@ __global__ __launch_bounds__(1024) void ln_fwd_lora_kernel(const TIn* __restrict
   }
 }
 
+// The same down-projection + mix for a layer whose input is NOT a LayerNorm output (lin2 of the MLP reads GELU(lin1)):
+// x bf16 [rows, C] -> a [rows, R], U [rows, 2R]. One wave per row (16-byte loads, the row is read once, contiguous 1 KB per
+// wave-instruction), A as bf16 in LDS, halving butterfly, mix through LDS - replaces skinny_nt (18.7 us at 8192 x 3072: its
+// 16-row MFMA tiles touch 16 rows x 128 B per request) + lora_mix_fwd.
+template <int R, bool MIX>
+__global__ __launch_bounds__(1024) void lora_down_mix_kernel(const bf16_t* __restrict__ x, int64_t ldx, int64_t rows, int C, const float* __restrict__ A,
+                                                             int64_t half, int n_groups, float* __restrict__ a_out, const float* __restrict__ wx,
+                                                             const float* __restrict__ wy, float* __restrict__ U) {
+  extern __shared__ __align__(16) unsigned char ln_lds[];
+  bf16_t* Al = reinterpret_cast<bf16_t*>(ln_lds);                                 // [G][R][C] bf16
+  float* al = reinterpret_cast<float*>(ln_lds + (size_t)n_groups * R * C * 2);    // [8][2][R]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int g = 0;
+  int64_t row;
+  bool valid;
+  if (n_groups == 2) {
+    g = w & 1;
+    const int64_t t = 8 * (int64_t)blockIdx.x + (w >> 1);
+    valid = t < half;
+    row = g * half + t;
+  } else {
+    row = (int64_t)blockIdx.x * 16 + w;
+    valid = row < rows;
+  }
+  const int n8 = C >> 3;                       // 16-byte chunks per row
+  constexpr int NCH = 8;                       // up to 8 chunks per lane: C <= 4096
+  u32x4_t v[NCH];
+  if (valid) {
+    const bf16_t* xr = x + row * ldx;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c8 = lane + 64 * i;
+      if (c8 < n8) v[i] = *reinterpret_cast<const u32x4_t*>(xr + 8 * c8);
+    }
+  }
+  {
+    const int tot4 = n_groups * R * (C >> 2);
+    for (int i = threadIdx.x; i < tot4; i += 1024) {
+      const float4 t = *reinterpret_cast<const float4*>(A + 4 * (int64_t)i);
+      u32x2_t wv;
+      wv.x = pack_bf16x2(t.x, t.y);
+      wv.y = pack_bf16x2(t.z, t.w);
+      *reinterpret_cast<u32x2_t*>(Al + 4 * (int64_t)i) = wv;
+    }
+  }
+  __syncthreads();
+  float p[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) p[j] = 0.f;
+  if (valid) {
+    const bf16_t* Ag = Al + (size_t)g * R * C;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c8 = lane + 64 * i;
+      if (c8 < n8) {
+        const float o[8] = {bf16_lo(v[i].x), bf16_hi(v[i].x), bf16_lo(v[i].y), bf16_hi(v[i].y), bf16_lo(v[i].z), bf16_hi(v[i].z), bf16_lo(v[i].w), bf16_hi(v[i].w)};
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const u32x4_t av = *reinterpret_cast<const u32x4_t*>(Ag + (size_t)j * C + 8 * c8);
+          p[j] = fmaf(o[0], bf16_lo(av.x), fmaf(o[1], bf16_hi(av.x), fmaf(o[2], bf16_lo(av.y), fmaf(o[3], bf16_hi(av.y),
+                 fmaf(o[4], bf16_lo(av.z), fmaf(o[5], bf16_hi(av.z), fmaf(o[6], bf16_lo(av.w), fmaf(o[7], bf16_hi(av.w), p[j]))))))));
+        }
+      }
+    }
+  }
+  int jb = 0, off = 32;
+#pragma unroll
+  for (int n = R; n > 1; n >>= 1, off >>= 1) {
+    const bool up = (lane & off) != 0;
+#pragma unroll
+    for (int i = 0; i < n / 2; ++i) {
+      const float send = up ? p[i] : p[i + n / 2];
+      const float recv = __shfl_xor(send, off, 64);
+      p[i] = (up ? p[i + n / 2] : p[i]) + recv;
+    }
+    jb += up ? n / 2 : 0;
+  }
+  for (; off > 0; off >>= 1) p[0] += __shfl_xor(p[0], off, 64);
+  const bool writer = (lane & (64 / R - 1)) == 0;
+  if (valid && writer) a_out[row * R + jb] = p[0];
+  if (MIX) {
+    if (writer) al[((w >> 1) * 2 + g) * R + jb] = p[0];
+    __syncthreads();
+    if (valid && lane < 2 * R) {
+      const float fx = wx[0], fy = wy[0];
+      const int jj = lane < R ? lane : lane - R;
+      const float ax = al[((w >> 1) * 2 + 0) * R + jj], ay = al[((w >> 1) * 2 + 1) * R + jj];
+      float u;
+      if (g == 0) u = lane < R ? fx * ax : (1.f - fx) * ay;
+      else u = lane < R ? (1.f - fy) * ax : fy * ay;
+      U[row * 2 * R + lane] = u;
+    }
+  }
+}
+
 // dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)) [+ dres]; optional bf16 copy of dx;
 // optional dgamma/dbeta accumulation (float atomics, one add per column per wave).
 // NVL = float4 chunks per lane (C <= 256 * NVL): the per-row register arrays are sized for the row at hand, which keeps
@@ -363,6 +458,32 @@ extern "C" int mfnet_layernorm_fwd_lora(const void* x, int x_dtype, int64_t ldx,
 #undef LN_LORA_N
 #undef LN_LORA
   MF_LAUNCH_CHECK("layernorm_fwd_lora");
+  return MFNET_OK;
+}
+
+extern "C" int mfnet_lora_down_mix(const void* x, int64_t ldx, int64_t rows, int64_t C, const float* A, int64_t a_group_stride, int n_groups, int R,
+                                   float* a_out, const float* wx, const float* wy, float* U, hipStream_t stream) {
+  MF_CHECK_ARG(x && A && a_out, "lora_down_mix: null pointer");
+  MF_CHECK_ARG(rows >= 0 && C > 0 && C % 8 == 0 && C <= 4096 && ldx % 8 == 0 && ldx >= C && (uintptr_t)x % 16 == 0 && (uintptr_t)A % 16 == 0,
+               "lora_down_mix: C=%lld must be a multiple of 8 and <= 4096 (16-byte aligned rows)", (long long)C);
+  MF_CHECK_ARG(R == 4 || R == 8, "lora_down_mix: R=%d (4 and 8 are built)", R);
+  MF_CHECK_ARG(n_groups == 1 || (n_groups == 2 && rows % 2 == 0 && a_group_stride == (int64_t)R * C),
+               "lora_down_mix: one group, or two contiguous groups [2][R][C] of rows/2 rows each");
+  MF_CHECK_ARG(!U || (wx && wy && n_groups == 2), "lora_down_mix: the cross-modal mix needs wx, wy and two groups");
+  const size_t lds = (size_t)n_groups * R * C * 2 + 8 * 2 * R * sizeof(float);
+  MF_CHECK_ARG(lds <= 64 * 1024, "lora_down_mix: G*R*C = %lld does not fit the 64 KB LDS image", (long long)n_groups * R * C);
+  if (rows == 0) return MFNET_OK;
+  const int64_t half = rows / 2;
+  const int64_t nblk = n_groups == 2 ? ceil_div64(half, 8) : ceil_div64(rows, 16);
+  MF_CHECK_ARG(nblk < (1ll << 31), "lora_down_mix: too many rows");
+  dim3 grid((unsigned)nblk), block(1024);
+#define LDM(RR, MX) hipLaunchKernelGGL((lora_down_mix_kernel<RR, MX>), grid, block, lds, stream, (const bf16_t*)x, ldx, rows, (int)C, A, half, n_groups, a_out, wx, wy, U)
+  if (R == 8 && U) LDM(8, true);
+  else if (R == 8) LDM(8, false);
+  else if (U) LDM(4, true);
+  else LDM(4, false);
+#undef LDM
+  MF_LAUNCH_CHECK("lora_down_mix");
   return MFNET_OK;
 }
 

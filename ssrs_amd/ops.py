@@ -77,6 +77,19 @@ def layernorm_fwd_lora(x, gamma, beta, eps, A, wx=None, wy=None):
     return y, mean, rstd, a, U
 
 
+def lora_down_mix(x, A, wx=None, wy=None):
+    """a = x @ A_g^T for a bf16 token matrix x [rows, C] (A fp32 [G, R, C]; G = 2: first half of the rows is modality x) and, with
+    wx / wy, the mixed factor U [rows, 2R] of lora.Linear, in one launch. -> (a, U | None)."""
+    _chk(x, A, wx, wy)
+    x2, rows, C, ldx = _rows2d(x)
+    assert x.dtype == torch.bfloat16 and A.dim() == 3 and A.is_contiguous() and A.dtype == torch.float32 and A.shape[2] == C
+    G, R = A.shape[0], A.shape[1]
+    a = torch.empty((rows, R), dtype=torch.float32, device=x.device)
+    U = torch.empty((rows, 2 * R), dtype=torch.float32, device=x.device) if wx is not None else None
+    call("mfnet_lora_down_mix", x2.data_ptr(), ldx, rows, C, A.data_ptr(), R * C, G, R, a.data_ptr(), _p(wx), _p(wy), _p(U), _stream(x))
+    return a, U
+
+
 def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, want_f32=True, want_bf16=False, dgamma=None, dbeta=None):
     """dx = LN'(dy) [+ dres]; returns (dx_f32 | None, dx_bf16 | None). dgamma/dbeta are accumulated into."""
     _chk(dy, x, mean, rstd, gamma, dres)

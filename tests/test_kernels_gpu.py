@@ -84,6 +84,24 @@ def test_layernorm_fwd_with_lora_down_projection(ops, rows, C, R, mix):
     assert rel_err(a1, yd @ Ab[0].t()) < 1e-5
 
 
+@pytest.mark.parametrize("rows,C,R,mix", [(8192, 3072, 4, True), (512, 768, 8, False), (36, 128, 4, True), (64, 1024, 8, False)])
+def test_lora_down_projection_and_mix_in_one_launch(ops, rows, C, R, mix):
+    x = rnd(rows, C, seed=1).to(torch.bfloat16)
+    A = 0.05 * rnd(2, R, C, seed=4)
+    wx, wy = torch.tensor([0.3], device="cuda"), torch.tensor([0.8], device="cuda")
+    a, U = ops.lora_down_mix(x, A, wx if mix else None, wy if mix else None)
+    half = rows // 2
+    xd, Ab = x.double(), A.to(torch.bfloat16).double()
+    ax, ay = xd[:half] @ Ab[0].t(), xd[half:] @ Ab[1].t()
+    assert rel_err(a, torch.cat([ax, ay])) < 1e-5
+    if mix:
+        assert rel_err(U, torch.cat([torch.cat([0.3 * ax, 0.7 * ay], 1), torch.cat([(1 - 0.8) * ax, 0.8 * ay], 1)])) < 1e-5
+        if half % 16 == 0:
+            assert rel_err(U, ops.lora_mix_fwd(ops.skinny_nt(x, A, rows_per_group=half).contiguous(), wx, wy)) < 1e-5
+    else:
+        assert U is None
+
+
 # ------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(8192, 768, 768), (1024, 2304, 768), (512, 768, 3072), (800, 192, 768),
                                    (333, 256, 2304), (128, 128, 64), (5000, 3072, 768)])
