@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmfnet_hip.so")
+LIB_PATH = os.environ.get("MFNET_HIP_LIB") or os.path.join(_HERE, "libmfnet_hip.so")     # override: A/B runs of two builds
 
 F32, BF16 = 0, 1
 

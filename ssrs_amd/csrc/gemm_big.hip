@@ -139,19 +139,43 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
 #endif
     if (t + C::STAGES - 1 < nt) stage(t + C::STAGES - 1, (t + C::STAGES - 1) % C::STAGES);
     const unsigned char* base = lds + (t % C::STAGES) * C::STAGE_BYTES;
+    if (NF <= 6) {
+      // both k-steps' fragments requested before the first MFMA (2 x (4 + NF) ds_read_b128 in flight, 80 VGPRs at NF = 6): the
+      // second k-step's LDS reads run under the first one's MFMAs. Left to itself hipcc keeps 6 fragment registers and waits
+      // lgkmcnt(0) every 8 MFMAs (148 VGPRs of the 256 this kernel may use at 2 waves / SIMD).
+      bf16x8_t xf[2][4], wf[2][NF];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t xf[4], wf[NF];
-      const int ch = fq + 4 * ks;
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ch = fq + 4 * ks;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8_t*>(base + x_off[i] + ((ch ^ x_sw[i]) << 4));
+        for (int i = 0; i < 4; ++i) xf[ks][i] = *reinterpret_cast<const bf16x8_t*>(base + x_off[i] + ((ch ^ x_sw[i]) << 4));
 #pragma unroll
-      for (int f = 0; f < NF; ++f) wf[f] = *reinterpret_cast<const bf16x8_t*>(base + w_off[f] + ((ch ^ w_sw[f]) << 4));
+        for (int f = 0; f < NF; ++f) wf[ks][f] = *reinterpret_cast<const bf16x8_t*>(base + w_off[f] + ((ch ^ w_sw[f]) << 4));
+      }
 #pragma unroll
-      for (int f = 0; f < NF; ++f)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-          acc[f][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f], xf[mi], acc[f][mi], 0, 0, 0);
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+            acc[f][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][f], xf[ks][mi], acc[f][mi], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (4 + NF), 0);      // all DS reads of the tile first ...
+      __builtin_amdgcn_sched_group_barrier(0x008, 8 * NF, 0);            // ... then the MFMAs (hipcc counts lgkmcnt per operand)
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t xf[4], wf[NF];
+        const int ch = fq + 4 * ks;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8_t*>(base + x_off[i] + ((ch ^ x_sw[i]) << 4));
+#pragma unroll
+        for (int f = 0; f < NF; ++f) wf[f] = *reinterpret_cast<const bf16x8_t*>(base + w_off[f] + ((ch ^ w_sw[f]) << 4));
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+            acc[f][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f], xf[mi], acc[f][mi], 0, 0, 0);
+      }
     }
   }
 
