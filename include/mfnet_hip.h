@@ -186,14 +186,16 @@ int mfnet_transpose_bf16(const void* x, int64_t ld, void* y, int64_t M, int64_t 
  * strides ldy / ldx), fp32 result: the wgrad of every trainable conv / linear of the decoder, FPN and adapters
  * (what autograd's conv / linear backward computes for unetformer_mmsam.py:43-84, adapter.py:17-25). The row range
  * is cut into `splits` (mfnet_gemm_tn_splits gives a good count); split s writes its partial [N][ldo] tile at
- * out + s*N*ldo, to be summed by mfnet_reduce_splits (splits == 1: out is the result). */
+ * out + s*N*ldo, to be summed by mfnet_reduce_splits (splits == 1: out is the result).
+ * bias_part (nullable): [splits][N] fp32, row s = column sums of dy over split s's rows - the bias gradient of the same
+ * layer from the fragments already in registers (its partial rows are summed like the weight partials). */
 int mfnet_gemm_tn_bf16(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t M, int64_t N, int64_t K,
-                       float* out, int64_t ldo, int splits, hipStream_t stream);
+                       float* out, int64_t ldo, int splits, float* bias_part, hipStream_t stream);
 /* n_groups independent products in one launch: group g multiplies rows [g*M, (g+1)*M) of dy and x (M = rows per group);
  * partial tile (split s, group g) goes to out + (s*n_groups + g)*N*ldo. The per-modality adapter weight gradients
- * (adapter.py:13-14 D_fc1 / D_fc2 of Img_ / DSM_ and MLPx_ / MLPy_Adapter). */
+ * (adapter.py:13-14 D_fc1 / D_fc2 of Img_ / DSM_ and MLPx_ / MLPy_Adapter). bias_part (nullable): [splits][n_groups][N]. */
 int mfnet_gemm_tn_bf16_grouped(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t M, int64_t N, int64_t K,
-                               float* out, int64_t ldo, int splits, int n_groups, hipStream_t stream);
+                               float* out, int64_t ldo, int splits, int n_groups, float* bias_part, hipStream_t stream);
 int64_t mfnet_gemm_tn_splits(int64_t M, int64_t N, int64_t K);
 int mfnet_reduce_splits(const float* partial, float* out, int64_t n, int splits, float scale, int accumulate, hipStream_t stream);
 

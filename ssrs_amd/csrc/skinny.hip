@@ -336,7 +336,7 @@ extern "C" int mfnet_skinny_tn(const void* Y, int64_t ldy, const float* U, int64
 // sums them), exactly like the split-K mode of mfnet_gemm_bf16.
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ DY, int64_t ldy, const bf16_t* __restrict__ X, int64_t ldx,
                                                       int64_t M, int N, int K, int64_t rows_per_split, float* __restrict__ out, int64_t ldo,
-                                                      int splits) {
+                                                      int splits, float* __restrict__ bias_part) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[4][2][32 * 128];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
@@ -352,6 +352,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
   int64_t r_end = r_begin + rows_per_split;
   if (r_end > M) r_end = M;
   out += (int64_t)blockIdx.z * N * ldo;
+  // bias gradient = column sums of dy over the same rows: the wave that owns k-tile 0 multiplies its dy fragments by a
+  // fragment of ones as well (4 more MFMAs per step) and writes the partial row [N] of this (split, group)
+  const bool want_b = bias_part != nullptr && k0 == 0;
+  f32x4_t accb[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) accb[a] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  bf16x8_t ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
   unsigned char* img_a = lds[wave][0];
   unsigned char* img_b = lds[wave][1];
   const int srow = lane >> 3, sch = lane & 7;
@@ -399,6 +408,20 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+    if (want_b) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], ones, accb[a], 0, 0, 0);
+    }
+  }
+  if (want_b && fr == 0) {
+    float* bo = bias_part + (int64_t)blockIdx.z * N;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 16 * a + 4 * fq + r;
+        if (n < N) bo[n] = accb[a][r];
+      }
   }
   // acc[a][b][r] = out[n0 + 16 a + 4 fq + r][k0 + 16 b + fr]
 #pragma unroll
@@ -426,7 +449,7 @@ extern "C" int64_t mfnet_gemm_tn_splits(int64_t M, int64_t N, int64_t K) {
 }
 
 static int gemm_tn_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t M, int64_t N, int64_t K,
-                          float* out, int64_t ldo, int splits, int n_groups, hipStream_t stream) {
+                          float* out, int64_t ldo, int splits, int n_groups, float* bias_part, hipStream_t stream) {
   MF_CHECK_ARG(dy && x && out, "gemm_tn: null pointer");
   MF_CHECK_ARG(n_groups >= 1 && (int64_t)n_groups * splits <= 65535, "gemm_tn: bad group count");
   MF_CHECK_ARG(M > 0 && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0, "gemm_tn: N=%lld and K=%lld must be multiples of 8", (long long)N, (long long)K);
@@ -436,19 +459,19 @@ static int gemm_tn_launch(const void* dy, int64_t ldy, const void* x, int64_t ld
   int64_t rps = ceil_div64(ceil_div64(M, splits), 32) * 32;
   dim3 grid((unsigned)ceil_div64(K, 256), (unsigned)ceil_div64(N, 64), (unsigned)(splits * n_groups));
   MF_CHECK_ARG(grid.y <= 65535, "gemm_tn: N too large");
-  hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, stream, (const bf16_t*)dy, ldy, (const bf16_t*)x, ldx, M, (int)N, (int)K, rps, out, ldo, splits);
+  hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, stream, (const bf16_t*)dy, ldy, (const bf16_t*)x, ldx, M, (int)N, (int)K, rps, out, ldo, splits, bias_part);
   MF_LAUNCH_CHECK("gemm_tn");
   return MFNET_OK;
 }
 
 extern "C" int mfnet_gemm_tn_bf16(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t M, int64_t N, int64_t K,
-                                  float* out, int64_t ldo, int splits, hipStream_t stream) {
-  return gemm_tn_launch(dy, ldy, x, ldx, M, N, K, out, ldo, splits, 1, stream);
+                                  float* out, int64_t ldo, int splits, float* bias_part, hipStream_t stream) {
+  return gemm_tn_launch(dy, ldy, x, ldx, M, N, K, out, ldo, splits, 1, bias_part, stream);
 }
 
 // n_groups independent products in one launch: group g takes rows [g*M, (g+1)*M) of dy and x (M = rows PER GROUP) and
 // writes its partial tiles to out + (s*n_groups + g)*N*ldo, s < splits - the two modalities' adapter weight gradients.
 extern "C" int mfnet_gemm_tn_bf16_grouped(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t M, int64_t N, int64_t K,
-                                          float* out, int64_t ldo, int splits, int n_groups, hipStream_t stream) {
-  return gemm_tn_launch(dy, ldy, x, ldx, M, N, K, out, ldo, splits, n_groups, stream);
+                                          float* out, int64_t ldo, int splits, int n_groups, float* bias_part, hipStream_t stream) {
+  return gemm_tn_launch(dy, ldy, x, ldx, M, N, K, out, ldo, splits, n_groups, bias_part, stream);
 }

@@ -203,13 +203,13 @@ class FpnFusionFn(torch.autograd.Function):
             # fpn2
             dY = dr[m][1].view(M3, 4 * C)
             ops.gemm(dY, _wb_ctT(f2[0].weight), residual=dd, out=dd)
-            _put(gd, f2[0].weight, _ct_grad(ops.gemm_tn(dY, dm, lazy=True), f2[0].weight))
-            _put(gd, f2[0].bias, ops.bias_grad(dY.view(4 * M3, C)))
+            dw, dbias = _tn_taps(dY, dm, C)
+            _put(gd, f2[0].weight, _ct_grad(dw, f2[0].weight)); _put(gd, f2[0].bias, dbias)
             # fpn1: second ConvT -> GELU -> norm -> first ConvT
             dY2 = dr[m][0].view(4 * M3, 4 * C)
             dn1 = ops.gemm(dY2, _wb_ctT(f1[3].weight), act=2, aux=s["n1"])
-            _put(gd, f1[3].weight, _ct_grad(ops.gemm_tn(dY2, s["a1"], lazy=True), f1[3].weight))
-            _put(gd, f1[3].bias, ops.bias_grad(dY2.view(16 * M3, C)))
+            dw, dbias = _tn_taps(dY2, s["a1"], C)
+            _put(gd, f1[3].weight, _ct_grad(dw, f1[3].weight)); _put(gd, f1[3].bias, dbias)
             if m == "x":
                 ln = f1[1].ln
                 dgam = ops.zeros(C, db.device)
@@ -221,9 +221,16 @@ class FpnFusionFn(torch.autograd.Function):
                 _put(gd, f1[1].weight, dgam); _put(gd, f1[1].bias, dbet)
             dY1 = dt1.view(M3, 4 * C)
             ops.gemm(dY1, _wb_ctT(f1[0].weight), residual=dd, out=dd)
-            _put(gd, f1[0].weight, _ct_grad(ops.gemm_tn(dY1, dm, lazy=True), f1[0].weight))
-            _put(gd, f1[0].bias, ops.bias_grad(dY1.view(4 * M3, C)))
+            dw, dbias = _tn_taps(dY1, dm, C)
+            _put(gd, f1[0].weight, _ct_grad(dw, f1[0].weight)); _put(gd, f1[0].bias, dbias)
         return (ddeep.view(2 * B, h, w, C), None, None) + _grads(plist, gd)
+
+
+def _tn_taps(dY, x, C):
+    """weight gradient of a 2x2 / stride-2 transposed conv as one TN product over dY [M, 4C] (4 taps side by side), with the
+    bias gradient - the column sums of dY folded over the 4 taps - from the same launch."""
+    dw, dbias = ops.gemm_tn(dY, x, lazy=True, want_bias=True)
+    return dw, ops.SplitSum(dbias.part.view(-1, C))
 
 
 # ---------------------------------------------------------------------------------------------- ConvBN 1x1 (decoder.pre_conv)
@@ -363,9 +370,11 @@ class BlockFn(torch.autograd.Function):
         d_bf = ops.cast(dout, BF)
         # ---- Mlp branch
         dhid = ops.gemm(d_bf, _wb(_w2(mlp.fc2.weight).t()), act=4, aux=hid)
-        _put(gd, mlp.fc2.weight, ops.gemm_tn(d_bf, hid, lazy=True)); _put(gd, mlp.fc2.bias, ops.bias_grad(d_bf))
+        dw, dbias = ops.gemm_tn(d_bf, hid, lazy=True, want_bias=True)
+        _put(gd, mlp.fc2.weight, dw); _put(gd, mlp.fc2.bias, dbias)
         dn2 = ops.gemm(dhid, _wb(_w2(mlp.fc1.weight).t()))
-        _put(gd, mlp.fc1.weight, ops.gemm_tn(dhid, n2b, lazy=True)); _put(gd, mlp.fc1.bias, ops.bias_grad(dhid))
+        dw, dbias = ops.gemm_tn(dhid, n2b, lazy=True, want_bias=True)
+        _put(gd, mlp.fc1.weight, dw); _put(gd, mlp.fc1.bias, dbias)
         dx1b, dg, dbt = _bn_bwd(dn2, x1, m2, r2, blk.norm2, training)
         _put(gd, blk.norm2.weight, dg); _put(gd, blk.norm2.bias, dbt)
         dx1 = ops.add3(dout, dx1b)

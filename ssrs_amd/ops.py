@@ -599,9 +599,10 @@ def transpose_pad(x, mult=64):
     return y
 
 
-def gemm_tn_grouped(dy, x, n_groups):
+def gemm_tn_grouped(dy, x, n_groups, want_bias=False):
     """n_groups independent dW_g[n,k] = sum over the rows of group g (M / n_groups consecutive rows each) of dy[m,n] x[m,k]
-    in one launch -> SplitSum of shape [G, N, K] (index it per group and hand the pieces to deliver)."""
+    in one launch -> SplitSum of shape [G, N, K] (index it per group and hand the pieces to deliver). want_bias: also the
+    column sums of dy per group (the bias gradients), from the same launch -> (dW, db) with db a SplitSum [G, N]."""
     _chk(dy, x)
     assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.stride(-1) == 1 and x.stride(-1) == 1
     d2, M, N, ldy = _rows2d(dy)
@@ -610,14 +611,18 @@ def gemm_tn_grouped(dy, x, n_groups):
     Mg = M // n_groups
     splits = int(_lib.lib().mfnet_gemm_tn_splits(Mg, N, K * n_groups))
     part = torch.empty((splits, n_groups, N, K), dtype=torch.float32, device=dy.device)
-    call("mfnet_gemm_tn_bf16_grouped", d2.data_ptr(), ldy, x2.data_ptr(), ldx, Mg, N, K, part.data_ptr(), K, splits, n_groups, _stream(dy))
-    return SplitSum(part)
+    bpart = torch.empty((splits, n_groups, N), dtype=torch.float32, device=dy.device) if want_bias else None
+    call("mfnet_gemm_tn_bf16_grouped", d2.data_ptr(), ldy, x2.data_ptr(), ldx, Mg, N, K, part.data_ptr(), K, splits, n_groups,
+         bpart.data_ptr() if want_bias else None, _stream(dy))
+    return (SplitSum(part), SplitSum(bpart)) if want_bias else SplitSum(part)
 
 
-def gemm_tn(dy, x, lazy=False):
+def gemm_tn(dy, x, lazy=False, want_bias=False):
     """dW[n,k] = sum_m dy[m,n] x[m,k]  (fp32 [N,K]); both bf16 row-major with M leading (views with a row
     stride are fine). The reduction runs over the rows (pixels / tokens): it is cut into splits whose partial
-    tiles one small kernel sums - or, with lazy, the gradient delivery does (returns a SplitSum)."""
+    tiles one small kernel sums - or, with lazy, the gradient delivery does (returns a SplitSum). want_bias: the launch
+    also leaves the column sums of dy (the layer's bias gradient) -> (dW, db), db always a SplitSum over [splits, N]
+    partial rows (view its .part to fold further, e.g. the 4 taps of a transposed conv)."""
     _chk(dy, x)
     assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.stride(-1) == 1 and x.stride(-1) == 1
     d2, M, N, ldy = _rows2d(dy)
@@ -625,14 +630,17 @@ def gemm_tn(dy, x, lazy=False):
     assert M == M2
     splits = int(_lib.lib().mfnet_gemm_tn_splits(M, N, K))
     part = torch.empty((splits, N, K), dtype=torch.float32, device=dy.device)
-    call("mfnet_gemm_tn_bf16", d2.data_ptr(), ldy, x2.data_ptr(), ldx, M, N, K, part.data_ptr(), K, splits, _stream(dy))
+    bpart = torch.empty((splits, N), dtype=torch.float32, device=dy.device) if want_bias else None
+    call("mfnet_gemm_tn_bf16", d2.data_ptr(), ldy, x2.data_ptr(), ldx, M, N, K, part.data_ptr(), K, splits,
+         bpart.data_ptr() if want_bias else None, _stream(dy))
     if splits == 1:
-        return part[0]
-    if lazy:
-        return SplitSum(part)
-    out = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-    call("mfnet_reduce_splits", part.data_ptr(), out.data_ptr(), out.numel(), splits, 1.0, 0, _stream(part))
-    return out
+        dW = part[0]
+    elif lazy:
+        dW = SplitSum(part)
+    else:
+        dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+        call("mfnet_reduce_splits", part.data_ptr(), dW.data_ptr(), dW.numel(), splits, 1.0, 0, _stream(part))
+    return (dW, SplitSum(bpart)) if want_bias else dW
 
 
 # ------------------------------------------------------------------------------------------ FPN / fusion / decoder

@@ -74,11 +74,9 @@ def _dense_fwd(x_bf, Wx, bx, Wy, by, half, act=False, residual=None, out=None, o
 def _dense_bwd(d_bf, x_bf, Wx, Wy, half, gelu_aux=None):
     """-> (dx bf16 for both halves, (dWx, dWy) fp32 split sums, (dbx, dby) fp32) for y = x W_g^T + b_g."""
     dx = ops.gemm_grouped(d_bf, _w2(Wx, Wy, transpose=True), rows_per_group=half, act=2 if gelu_aux is not None else 0, aux=gelu_aux)
-    dW = ops.gemm_tn_grouped(d_bf, x_bf, 2)                 # both modalities' products in one launch; summed by the delivery
-    if d_bf.is_contiguous() and d_bf.shape[1] % 4 == 0 and d_bf.shape[1] <= 1024:
-        db = ops.colsum(d_bf, 2, half)[0]                                                                  # [2, N], deterministic
-    else:
-        db = [ops.bias_grad(d_bf[:half]), ops.bias_grad(d_bf[half:])]
+    # both modalities' products in one launch, the bias gradients (column sums of d) from the same fragments; the partial
+    # tiles / rows of the row splits are summed by the delivery
+    dW, db = ops.gemm_tn_grouped(d_bf, x_bf, 2, want_bias=True)
     return dx, dW, db
 
 

@@ -40,7 +40,7 @@ def test_argument_errors_do_not_launch():
     rc = L.mfnet_gemm_bf16_grouped(16, 64, 16, 64, 4, 128, 64, 64, None, 0, 64, 2, 0, None, 0, None, 0, None, 0, 16, 0, 64, None)
     assert rc == -1 and b"group strides" in L.mfnet_last_error()
     # weight-gradient GEMM: N / K must be multiples of 8; split count helper is pure host code
-    rc = L.mfnet_gemm_tn_bf16(16, 64, 16, 64, 128, 60, 64, 16, 64, 1, None)
+    rc = L.mfnet_gemm_tn_bf16(16, 64, 16, 64, 128, 60, 64, 16, 64, 1, None, None)
     assert rc == -1 and b"multiples of 8" in L.mfnet_last_error()
     assert L.mfnet_gemm_tn_splits(65536, 64, 576) >= 2 and L.mfnet_gemm_tn_splits(100, 64, 64) == 1
     # gather: a segment with a null pointer / an accumulate into bf16 is refused

@@ -491,6 +491,16 @@ def test_gemm_tn_split_k(ops, M, N, K):
     ref = dy.double().t() @ x.double()
     assert got.shape == (N, K)
     assert rel_err(got, ref) < 1e-4
+    got2, db = ops.gemm_tn(dy, x, lazy=True, want_bias=True)       # bias gradient (column sums of dy) from the same launch
+    got2 = got2.materialize() if isinstance(got2, ops.SplitSum) else got2
+    assert rel_err(got2, got) < 1e-6                                # (the two reductions sum the split tiles in different orders)
+    assert db.shape == (N,) and rel_err(db.materialize(), dy.double().sum(0)) < 1e-5
+    if M % 2 == 0:
+        gw, gb = ops.gemm_tn_grouped(dy, x, 2, want_bias=True)
+        h = M // 2
+        assert rel_err(gw.materialize(), torch.stack([dy[:h].double().t() @ x[:h].double(), dy[h:].double().t() @ x[h:].double()])) < 1e-4
+        assert rel_err(gb.materialize(), torch.stack([dy[:h].double().sum(0), dy[h:].double().sum(0)])) < 1e-5
+        assert rel_err(gb[1].materialize(), dy[h:].double().sum(0)) < 1e-5
 
 
 # ------------------------------------------------------------------------------------------ batched strided copies
