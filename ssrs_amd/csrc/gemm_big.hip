@@ -91,6 +91,9 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
     dst_off[i] = __builtin_amdgcn_readfirstlane(j * 1024);
   }
   auto stage = [&](int kt, int buf) {
+#ifdef GEMM_NOLOAD      // diagnostic: only the first tiles are fetched - the main loop without its global traffic
+    if (kt >= C::STAGES) return;
+#endif
     unsigned char* base = lds + buf * C::STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < C::PPW; ++i)
@@ -123,45 +126,92 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  // ---- main loop over K-tiles: ring of STAGES buffers, tile t + STAGES - 1 requested while tile t is computed
+  // ---- main loop over K-tiles: ring of STAGES buffers filled by global_load_lds ahead of the MFMAs
   const int nt = p.K / BIG_BK;
+  if constexpr (NF <= 6) {
+    // Fragment registers are double-buffered at k-step granularity ACROSS the barrier: while the MFMAs of one k-step run, the
+    // ds_read_b128 of the next one are in flight - the second k-step of the tile, or (after the barrier that publishes tile
+    // t + 1) the first k-step of the next tile. (With all reads of a tile issued behind its barrier and waited for together,
+    // the 8 waves read LDS and then issue MFMAs in phase: a k-tile took ~1.8x its MFMA time.)
+    // Ring: tiles 0 .. STAGES-1 requested up front; at the barrier inside iteration t every wave holds all of tile t in
+    // registers, so tile t + STAGES goes into tile t's buffer.
 #pragma unroll
-  for (int s = 0; s < C::STAGES - 1; ++s)
-    if (s < nt) stage(s, s);
-  for (int t = 0; t < nt; ++t) {
-    // tile t has landed once at most the (STAGES-2) younger tiles of this wave are outstanding (vmcnt counts in issue order)
-    if (C::STAGES == 3 && t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();          // every wave's pieces of tile t are in LDS; every wave is done reading tile t-1's buffer
-    asm volatile("" ::: "memory");
-#ifdef GEMM_STAMPS
-    if (t == 0) MF_STAMP(1);
-#endif
-    if (t + C::STAGES - 1 < nt) stage(t + C::STAGES - 1, (t + C::STAGES - 1) % C::STAGES);
-    const unsigned char* base = lds + (t % C::STAGES) * C::STAGE_BYTES;
-    if (NF <= 6) {
-      // both k-steps' fragments requested before the first MFMA (2 x (4 + NF) ds_read_b128 in flight, 80 VGPRs at NF = 6): the
-      // second k-step's LDS reads run under the first one's MFMAs. Left to itself hipcc keeps 6 fragment registers and waits
-      // lgkmcnt(0) every 8 MFMAs (148 VGPRs of the 256 this kernel may use at 2 waves / SIMD).
-      bf16x8_t xf[2][4], wf[2][NF];
+    for (int s = 0; s < C::STAGES; ++s)
+      if (s < nt) stage(s, s);
+    bf16x8_t xa[4], wa[NF], xb[4], wb[NF];
+    auto rd = [&](const unsigned char* base, int ks, bf16x8_t (&x)[4], bf16x8_t (&w)[NF]) {
+      const int ch = fq + 4 * ks;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int ch = fq + 4 * ks;
+      for (int i = 0; i < 4; ++i) x[i] = *reinterpret_cast<const bf16x8_t*>(base + x_off[i] + ((ch ^ x_sw[i]) << 4));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xf[ks][i] = *reinterpret_cast<const bf16x8_t*>(base + x_off[i] + ((ch ^ x_sw[i]) << 4));
+      for (int f = 0; f < NF; ++f) w[f] = *reinterpret_cast<const bf16x8_t*>(base + w_off[f] + ((ch ^ w_sw[f]) << 4));
+    };
+    auto mm = [&](const bf16x8_t (&x)[4], const bf16x8_t (&w)[NF], int f0, int f1) {
 #pragma unroll
-        for (int f = 0; f < NF; ++f) wf[ks][f] = *reinterpret_cast<const bf16x8_t*>(base + w_off[f] + ((ch ^ w_sw[f]) << 4));
+      for (int f = 0; f < NF; ++f) {
+        if (f < f0 || f >= f1) continue;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          acc[f][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[f], x[mi], acc[f][mi], 0, 0, 0);
       }
+    };
+    // tile 0 landed: at most the younger tiles of this wave outstanding
+    if (nt >= C::STAGES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PPW * (C::STAGES - 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    MF_STAMP(1);
+    rd(lds, 0, xa, wa);
+    // (in each half the first MFMAs go ahead of the next reads: hipcc's wait for fragments whose reads crossed a loop edge or
+    // an asm statement is lgkmcnt(0) - it must not cover the reads just issued; the last tile is peeled so that no branch
+    // joins inside the body)
+    for (int t = 0; t + 1 < nt; ++t) {
+      const unsigned char* base = lds + (t % C::STAGES) * C::STAGE_BYTES;
+      mm(xa, wa, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      rd(base, 1, xb, wb);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(xa, wa, 1, NF);
+      __builtin_amdgcn_sched_barrier(0);
+      // tile t + 1 landed (tiles t + 2 .. t + STAGES - 1 may still be in flight) and this wave's reads of tile t returned
+#ifdef GEMM_NOWAIT      // diagnostic (wrong results): tiles are fetched but never waited for
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+      if (t + C::STAGES - 1 < nt && C::STAGES > 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::PPW * (C::STAGES - 2)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (t + C::STAGES < nt) stage(t + C::STAGES, t % C::STAGES);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(xb, wb, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      rd(lds + ((t + 1) % C::STAGES) * C::STAGE_BYTES, 0, xa, wa);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(xb, wb, 1, NF);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mm(xa, wa, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    rd(lds + ((nt - 1) % C::STAGES) * C::STAGE_BYTES, 1, xb, wb);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(xa, wa, 1, NF);
+    mm(xb, wb, 0, NF);
+  } else {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int f = 0; f < NF; ++f)
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-            acc[f][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][f], xf[ks][mi], acc[f][mi], 0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (4 + NF), 0);      // all DS reads of the tile first ...
-      __builtin_amdgcn_sched_group_barrier(0x008, 8 * NF, 0);            // ... then the MFMAs (hipcc counts lgkmcnt per operand)
-    } else {
+    for (int s = 0; s < C::STAGES - 1; ++s)
+      if (s < nt) stage(s, s);
+    for (int t = 0; t < nt; ++t) {
+      // tile t has landed once at most the (STAGES-2) younger tiles of this wave are outstanding (vmcnt counts in issue order)
+      if (C::STAGES == 3 && t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();          // every wave's pieces of tile t are in LDS; every wave is done reading tile t-1's buffer
+      asm volatile("" ::: "memory");
+#ifdef GEMM_STAMPS
+      if (t == 0) MF_STAMP(1);
+#endif
+      if (t + C::STAGES - 1 < nt) stage(t + C::STAGES - 1, (t + C::STAGES - 1) % C::STAGES);
+      const unsigned char* base = lds + (t % C::STAGES) * C::STAGE_BYTES;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8_t xf[4], wf[NF];

@@ -45,14 +45,17 @@ def run(M, N, K, kind):
     o = cfg["out"]
     lora = cfg.get("lora", False)
 
+    tile = TILE if TILE else {3072: 6, 768: 3, 2304: 9}[N]
+
     def launch():
         rc = L.mfnet_gemm_bf16_tiled(x.data_ptr(), K, w.data_ptr(), K, M, N, K, p(cfg.get("bias")), p(U) if lora else None, 8 if lora else 0,
                                p(V) if lora else None, V.stride(0) if lora else 0, M // 2 if lora else 0, 2 if lora else 1, 8 if lora else 0,
                                0.25, cfg.get("act", 0), p(cfg.get("aux")), N if cfg.get("aux") is not None else 0, p(cfg.get("pre")),
                                N if cfg.get("pre") is not None else 0, p(cfg.get("res")), N if cfg.get("res") is not None else 0, 0,
-                               o.data_ptr(), 1 if o.dtype == torch.bfloat16 else 0, N, 1, TILE, torch.cuda.current_stream().cuda_stream)
+                               o.data_ptr(), 1 if o.dtype == torch.bfloat16 else 0, N, 1, tile, torch.cuda.current_stream().cuda_stream)
         assert rc == 0, L.mfnet_last_error()
-    nwg = (M // 128) * (N // 128) if TILE < 0 else (M // 256) * (N // (32 * TILE))
+    tile = TILE if TILE else {3072: 6, 768: 3, 2304: 9}[N]
+    nwg = (M // 128) * (N // 128) if tile < 0 else (M // 256) * (N // (32 * tile))
     st = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
     L.mfnet_diag_set_stamps(None)
     for _ in range(5):
