@@ -57,13 +57,14 @@ __global__ __launch_bounds__(256, (NSG == 1 && HD <= 64) ? 4 : 2) void attn_fwd_
   unsigned char* G_lds = smem + regionA;                           // [nsg][128][32] bf16 indicator rows
 
   const int64_t row_base = (int64_t)gi * T;
-  const int64_t ld = 3 * (int64_t)g.D;
+  const int ld = 3 * g.D;                                          // (one image's qkv rows span < 2^31 elements)
+  const bf16_t* qkv_img = p.qkv + row_base * ld;
 
   // ---- this lane's query (column of every accumulator tile)
   const QueryPos qp = query_pos(g, wi, wj, qt0 + wave * 16 + fr);
   const bool wave_active = qt0 + wave * 16 < nq;                   // wave-uniform: waves without a query only stage
   bf16x8_t qf[KS];
-  att_load_row_frags<HD>(p.qkv + (row_base + qp.tok) * ld + head * HD, fq, qp.valid, qf);
+  att_load_row_frags<HD>(qkv_img + qp.tok * ld + head * HD, fq, qp.valid, qf);
   // this thread always stages 16-B chunk `ch` of a key row: the padded-key value of that chunk (the qkv bias,
   // rounded to bf16 like every other qkv entry) is kept in registers
   const int ch = tid % CHS, chl = ch < CHV ? ch : CHV - 1;         // slots >= CHV hold zeros (never loaded)
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256, (NSG == 1 && HD <= 64) ? 4 : 2) void attn_fwd_
       const int kg = kc + it * RPI + tid / CHS;
       int kh = 0, kw = 0;
       const int tok = kg < Nk ? key_token(g, wi, wj, kg, &kh, &kw) : -2;
-      const bf16_t* src = p.qkv + (row_base + max(tok, 0)) * ld + g.D + head * HD + chl * 8;
+      const bf16_t* src = qkv_img + (max(tok, 0) * ld + g.D + head * HD + chl * 8);
       kv[it] = *reinterpret_cast<const u32x4_t*>(src);
       vv[it] = *reinterpret_cast<const u32x4_t*>(src + g.D);
       kkind[it] = ch >= CHV ? 2 : (tok < 0 ? (tok == -2 ? 2 : 1) : 0);   // 0 real, 1 padded, 2 beyond the window / zero slot

@@ -61,7 +61,11 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : 2)) void attn_bw
   unsigned char* G_lds = smem + att_region_a(g.NT, ROWB);             // [nsg][128][32] bf16 indicator rows
 
   const int64_t row_base = (int64_t)gi * T;
-  const int64_t ld = 3 * (int64_t)g.D;
+  const int ld = 3 * g.D;                                          // (one image's qkv rows span < 2^31 elements)
+  const bf16_t* qkv_img = p.qkv + row_base * ld;
+  bf16_t* dqkv_img = p.dqkv + row_base * ld;
+  const bf16_t* dout_img = p.dout + row_base * g.D;
+  const bf16_t* out_img = p.out + row_base * g.D;
   const QueryPos qp = query_pos(g, wi, wj, qt0 + wave * 16 + fr);
   const bool wave_active = qt0 + wave * 16 < nq;
 
@@ -69,9 +73,9 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : 2)) void attn_bw
   float delta = 0.f, lse2 = 0.f;
   {
     bf16x8_t of[KS];
-    att_load_row_frags<HD>(p.qkv + (row_base + qp.tok) * ld + head * HD, fq, qp.valid, qf);
-    att_load_row_frags<HD>(p.dout + (row_base + qp.tok) * g.D + head * HD, fq, qp.valid, dof);
-    att_load_row_frags<HD>(p.out + (row_base + qp.tok) * g.D + head * HD, fq, qp.valid, of);
+    att_load_row_frags<HD>(qkv_img + qp.tok * ld + head * HD, fq, qp.valid, qf);
+    att_load_row_frags<HD>(dout_img + qp.tok * g.D + head * HD, fq, qp.valid, dof);
+    att_load_row_frags<HD>(out_img + qp.tok * g.D + head * HD, fq, qp.valid, of);
     lse2 = qp.valid ? p.lse[((int64_t)gi * g.heads + head) * T + qp.tok] * 1.4426950408889634f : 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : 2)) void attn_bw
       const int kg = kc + it * RPI + tid / CHS;
       int kh = 0, kw = 0;
       const int tok = kg < Nk ? key_token(g, wi, wj, kg, &kh, &kw) : -2;
-      const bf16_t* src = p.qkv + (row_base + max(tok, 0)) * ld + g.D + head * HD + chl * 8;
+      const bf16_t* src = qkv_img + max(tok, 0) * ld + g.D + head * HD + chl * 8;
       kv[it] = *reinterpret_cast<const u32x4_t*>(src);
       vv[it] = *reinterpret_cast<const u32x4_t*>(src + g.D);
       kkind[it] = ch >= CHV ? 2 : (tok < 0 ? (tok == -2 ? 2 : 1) : 0);
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : 2)) void attn_bw
     }
   }
   if (qp.valid) {
-    bf16_t* op = p.dqkv + (row_base + qp.tok) * ld + head * HD + 4 * fq;
+    bf16_t* op = dqkv_img + qp.tok * ld + head * HD + 4 * fq;
 #pragma unroll
     for (int u = 0; u < UT; ++u) {
       u32x2_t w;
@@ -316,14 +320,18 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 4 : (NSG == 4 ? 2 : 
   float* Twq = (float*)TqL_lds;                                  // ROWT: [64 queries][ATT_TS] w term / scale by key column
 
   const int64_t row_base = (int64_t)gi * T;
-  const int64_t ld = 3 * (int64_t)g.D;
+  const int ld = 3 * g.D;                                          // (one image's qkv rows span < 2^31 elements)
+  const bf16_t* qkv_img = p.qkv + row_base * ld;
+  bf16_t* dqkv_img = p.dqkv + row_base * ld;
+  const bf16_t* dout_img = p.dout + row_base * g.D;
+  const bf16_t* out_img = p.out + row_base * g.D;
 
   // this lane's key (column of S / dP tiles) and its indicator slots
   const QueryPos kp = query_pos(g, wi, wj, k0 + wave * 16 + fr);
   const bool wave_active = k0 + wave * 16 < nq;
   bf16x8_t kb[KS], vb[KS];
-  att_load_row_frags<HD>(p.qkv + (row_base + kp.tok) * ld + g.D + head * HD, fq, true, kb);
-  att_load_row_frags<HD>(p.qkv + (row_base + kp.tok) * ld + 2 * g.D + head * HD, fq, true, vb);
+  att_load_row_frags<HD>(qkv_img + kp.tok * ld + g.D + head * HD, fq, true, kb);
+  att_load_row_frags<HD>(qkv_img + kp.tok * ld + 2 * g.D + head * HD, fq, true, vb);
   bf16x8_t gk[NSG];
   {
     const int jh = g.KH - 1 - kp.qh, jw = g.KH + g.KW - 1 - kp.qw;
@@ -354,9 +362,9 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 4 : (NSG == 4 ? 2 : 
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const QueryPos qq = query_pos(g, wi, wj, qc + it * RPI + tid / CHS);
-      qv[it] = *reinterpret_cast<const u32x4_t*>(p.qkv + (row_base + qq.tok) * ld + head * HD + chl * 8);
-      dv_[it] = *reinterpret_cast<const u32x4_t*>(p.dout + (row_base + qq.tok) * g.D + head * HD + chl * 8);
-      ov[it] = *reinterpret_cast<const u32x4_t*>(p.out + (row_base + qq.tok) * g.D + head * HD + chl * 8);
+      qv[it] = *reinterpret_cast<const u32x4_t*>(qkv_img + qq.tok * ld + head * HD + chl * 8);
+      dv_[it] = *reinterpret_cast<const u32x4_t*>(dout_img + qq.tok * g.D + head * HD + chl * 8);
+      ov[it] = *reinterpret_cast<const u32x4_t*>(out_img + qq.tok * g.D + head * HD + chl * 8);
       lsev[it] = p.lse[((int64_t)gi * g.heads + head) * T + qq.tok];
       qok[it] = qq.valid;
     }
@@ -473,7 +481,7 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 4 : (NSG == 4 ? 2 : 
     }
   }
   if (kp.valid) {
-    bf16_t* op = p.dqkv + (row_base + kp.tok) * ld + g.D + head * HD + 4 * fq;
+    bf16_t* op = dqkv_img + kp.tok * ld + g.D + head * HD + 4 * fq;
 #pragma unroll
     for (int u = 0; u < UT; ++u) {
       u32x2_t w;

@@ -43,6 +43,12 @@ struct AttnGeom {
 
 struct QueryPos { int valid, tok, qh, qw; };
 
+// k / d for 0 <= k < 2^20, 1 <= d <= 128 with one reciprocal and one multiply instead of the ~25-instruction integer
+// division: (k + 0.5) / d is at least 0.5 / d away from an integer while the float product is off by < k * 2.4e-7.
+__device__ __forceinline__ int att_div(int k, int d) {
+  return (int)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)d));
+}
+
 // query index qi inside (window wi,wj) -> token + in-window coordinates
 __device__ __forceinline__ QueryPos query_pos(const AttnGeom& g, int wi, int wj, int qi) {
   QueryPos r;
@@ -53,7 +59,7 @@ __device__ __forceinline__ QueryPos query_pos(const AttnGeom& g, int wi, int wj,
   }
   r.valid = qi < rh * rw;
   const int q = r.valid ? qi : 0;
-  r.qh = q / rw; r.qw = q - r.qh * rw;
+  r.qh = att_div(q, rw); r.qw = q - r.qh * rw;
   r.tok = (oh + r.qh) * g.Sw + (ow + r.qw);
   return r;
 }
@@ -63,7 +69,7 @@ __device__ __forceinline__ int num_queries(const AttnGeom& g, int wi, int wj) {
 }
 // key index k (row-major over KH x KW) -> token or -1 for a padded position
 __device__ __forceinline__ int key_token(const AttnGeom& g, int wi, int wj, int k, int* kh, int* kw) {
-  *kh = k / g.KW; *kw = k - *kh * g.KW;
+  *kh = att_div(k, g.KW); *kw = k - *kh * g.KW;
   const int y = (g.ws > 0 ? wi * g.ws : 0) + *kh, x = (g.ws > 0 ? wj * g.ws : 0) + *kw;
   return (y < g.Sh && x < g.Sw) ? y * g.Sw + x : -1;
 }
@@ -87,11 +93,11 @@ __device__ __forceinline__ s16x4_t att_tr_read(const unsigned char* lds_addr) {
 // blockIdx.x -> (window, first query) over the (window, 64-query tile) pairs that exist
 __device__ __forceinline__ void att_locate_tile(const AttnGeom& g, int t, int* wi, int* wj, int* qt0) {
   int i = 0, j = 0;
-  for (int w = 0; w < g.nWh * g.nWw; ++w) {
-    i = w / g.nWw; j = w - i * g.nWw;
+  for (int w = 0; w + 1 < g.nWh * g.nWw; ++w) {       // (the last window takes what is left)
     const int nt = (num_queries(g, i, j) + ATT_QT - 1) / ATT_QT;
     if (t < nt) break;
     t -= nt;
+    if (++j == g.nWw) { j = 0; ++i; }
   }
   *wi = i; *wj = j; *qt0 = t * ATT_QT;
 }
@@ -182,7 +188,7 @@ __device__ __forceinline__ void att_slot_fragments(const AttnGeom& g, const floa
 __device__ __forceinline__ void att_stage_indicator(const AttnGeom& g, unsigned char* G_lds, int kc, int Nk, int nsg, int tid) {
   const int key = tid >> 1, kg = kc + key;
   int jh = -1, jw = -1;
-  if (kg < Nk) { const int kh = kg / g.KW, kw = kg - kh * g.KW; jh = g.KH - 1 - kh; jw = g.KH + g.KW - 1 - kw; }
+  if (kg < Nk) { const int kh = att_div(kg, g.KW), kw = kg - kh * g.KW; jh = g.KH - 1 - kh; jw = g.KH + g.KW - 1 - kw; }
   for (int cidx = (tid & 1) * 2 * nsg; cidx < ((tid & 1) + 1) * 2 * nsg; ++cidx) {
     const int c = cidx >> 2, c4 = cidx & 3, s0 = 32 * c + 8 * c4;
     u32x4_t w;

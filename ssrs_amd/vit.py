@@ -203,12 +203,14 @@ class _LoraAttnBranch(torch.autograd.Function):
             da = ops.skinny_nt(dqkv, _qkv_lora_V(Bx, By, D, r, transposed=True), scale=s, rows_per_group=half).contiguous()
             dVx, dVy = _tn_groups(dqkv, a, half, False, s)
             dAx, dAy = _tn_groups(ln, da, half, True)
-        dln = ops.gemm(dqkv, wT_bf16(attn.qkv.weight), U=da, V=_stack2("A", Ax, Ay, transpose=True), rows_per_group=half, n_groups=2)
-        dh, dh_bf = ops.layernorm_bwd(dln, h2, mean, rstd, blk.norm1.weight, dres=d2, want_bf16=True)
-        ops.remember_bf16_twin(dh, dh_bf)
         rows_q, rows_v = slice(0, D), slice(D, 2 * D)
         grads = deliver((Ax, Ay, Bx, By), (dAx, dAy, [(rows_q, dVx[:D, :r]), (rows_v, dVx[2 * D:, r:])],
                                            [(rows_q, dVy[:D, :r]), (rows_v, dVy[2 * D:, r:])]))
+        if not ctx.needs_input_grad[0]:          # first block over a frozen patch embedding: nothing upstream wants dh
+            return (None, None, None) + grads
+        dln = ops.gemm(dqkv, wT_bf16(attn.qkv.weight), U=da, V=_stack2("A", Ax, Ay, transpose=True), rows_per_group=half, n_groups=2)
+        dh, dh_bf = ops.layernorm_bwd(dln, h2, mean, rstd, blk.norm1.weight, dres=d2, want_bf16=True)
+        ops.remember_bf16_twin(dh, dh_bf)
         return (dh.view(dout.shape), None, None) + grads
 
 

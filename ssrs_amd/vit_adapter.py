@@ -120,6 +120,8 @@ class _AdapterAttnBranch(torch.autograd.Function):
         dxo, dW1, db1 = _dense_bwd(dpre, op, w1x, w1y, half)
         ops.add_bf16(dxo, d_bf, dop)                           # adapter skip: d o_proj = d + fc1-path
         grads = [dW1[0], db1[0], dW2[0], db2[0], dW1[1], db1[1], dW2[1], db2[1]]
+        if not ctx.needs_input_grad[0]:          # first block over a frozen patch embedding: the (frozen) attention needs no backward
+            return (None, None, None) + deliver(ctx.params, grads)
         dO = ops.gemm(dop, wT_bf16(attn.proj.weight))
         dqkv = ops.attn_bwd(qkv, attn.qkv.bias, tbl, tblT, o, dO, lse, 2 * B, Sh, Sw, heads, ws, Lh, Lw, hd ** -0.5)
         dln = ops.gemm(dqkv, wT_bf16(attn.qkv.weight))
