@@ -583,10 +583,14 @@ __device__ __forceinline__ int ext_map(int r, int n, int ext) {   // -> source i
   if (r < n) return r;
   return (ext && r == n) ? n - 2 : -1;
 }
+// K = 3 / 8: the taps of one kernel row are loaded together (clamped address, masked after the load) - with a runtime k and
+// `continue` around each tap the loop was one dependent L2 round trip per tap (64 of them for the GLA 8x8 kernel: 24 us on a
+// 64 KB map). K = 0: any k, the plain loop.
+template <int K>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                          float* __restrict__ y, const DwParams p) {
   extern __shared__ float wl[];      // [k*k][C]
-  const int kk = p.k * p.k;
+  const int k = K ? K : p.k, kk = k * k;
   for (int i = threadIdx.x; i < kk * p.C; i += 256) { const int tap = i / p.C, c = i - tap * p.C; wl[i] = w[c * kk + tap]; }
   __syncthreads();
   const int C4 = p.C >> 2;
@@ -597,25 +601,47 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
     const int xx = (int)(pix % p.W), yy = (int)((pix / p.W) % p.H);
     const int64_t b = pix / ((int64_t)p.W * p.H);
     float4 acc = bias ? reinterpret_cast<const float4*>(bias)[cg] : F4ZERO;
-    for (int ky = 0; ky < p.k; ++ky) {
-      const int sy = ext_map(yy + ky - p.pad, p.H, p.ext);
-      if (sy < 0) continue;
-      for (int kx = 0; kx < p.k; ++kx) {
-        const int sx = ext_map(xx + kx - p.pad, p.W, p.ext);
-        if (sx < 0) continue;
-        const float4 v = reinterpret_cast<const float4*>(x)[((b * p.H + sy) * p.W + sx) * C4 + cg];
-        acc = f4fma(v, reinterpret_cast<const float4*>(wl)[(ky * p.k + kx) * C4 + cg], acc);
+    if (K) {
+      constexpr int KU = K ? K : 1;
+#pragma unroll 2
+      for (int ky = 0; ky < KU; ++ky) {
+        const int sy = ext_map(yy + ky - p.pad, p.H, p.ext);
+        const int64_t rowb = (b * p.H + (sy < 0 ? 0 : sy)) * p.W;
+        float4 v[KU];
+        bool ok[KU];
+#pragma unroll
+        for (int kx = 0; kx < KU; ++kx) {
+          const int sx = ext_map(xx + kx - p.pad, p.W, p.ext);
+          ok[kx] = sy >= 0 && sx >= 0;
+          v[kx] = reinterpret_cast<const float4*>(x)[(rowb + (sx < 0 ? 0 : sx)) * C4 + cg];
+        }
+#pragma unroll
+        for (int kx = 0; kx < KU; ++kx) {
+          const float4 wv = reinterpret_cast<const float4*>(wl)[(ky * KU + kx) * C4 + cg];
+          if (ok[kx]) acc = f4fma(v[kx], wv, acc);
+        }
+      }
+    } else {
+      for (int ky = 0; ky < k; ++ky) {
+        const int sy = ext_map(yy + ky - p.pad, p.H, p.ext);
+        if (sy < 0) continue;
+        for (int kx = 0; kx < k; ++kx) {
+          const int sx = ext_map(xx + kx - p.pad, p.W, p.ext);
+          if (sx < 0) continue;
+          const float4 v = reinterpret_cast<const float4*>(x)[((b * p.H + sy) * p.W + sx) * C4 + cg];
+          acc = f4fma(v, reinterpret_cast<const float4*>(wl)[(ky * k + kx) * C4 + cg], acc);
+        }
       }
     }
     reinterpret_cast<float4*>(y)[i] = acc;
   }
 }
 // dx[y,x] = sum over the ext positions e that map to (y,x) of  sum_taps dy[e - tap + pad] * w[tap]
-template <bool DY_BF16>
+template <bool DY_BF16, int K>
 __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const void* __restrict__ dy, int dy_dt, const float* __restrict__ w,
                                                               float* __restrict__ dx, const DwParams p) {
   extern __shared__ float wl[];
-  const int kk = p.k * p.k;
+  const int k = K ? K : p.k, kk = k * k;
   for (int i = threadIdx.x; i < kk * p.C; i += 256) { const int tap = i / p.C, c = i - tap * p.C; wl[i] = w[c * kk + tap]; }
   __syncthreads();
   const int C4 = p.C >> 2;
@@ -631,13 +657,37 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const void* __rest
       const int py = ey ? p.H : yy;
       for (int ex = 0; ex < nx; ++ex) {
         const int px = ex ? p.W : xx;
-        for (int ky = 0; ky < p.k; ++ky) {
-          const int oy = py - ky + p.pad;
-          if (oy < 0 || oy >= p.H) continue;
-          for (int kx = 0; kx < p.k; ++kx) {
-            const int ox = px - kx + p.pad;
-            if (ox < 0 || ox >= p.W) continue;
-            acc = f4fma(ld4t<DY_BF16>(dy, ((b * p.H + oy) * p.W + ox) * C4 + cg), reinterpret_cast<const float4*>(wl)[(ky * p.k + kx) * C4 + cg], acc);
+        if (K) {
+          constexpr int KU = K ? K : 1;
+#pragma unroll 2
+          for (int ky = 0; ky < KU; ++ky) {
+            const int oy = py - ky + p.pad;
+            const bool oky = oy >= 0 && oy < p.H;
+            const int64_t rowb = (b * p.H + (oky ? oy : 0)) * p.W;
+            float4 v[KU];
+            bool ok[KU];
+#pragma unroll
+            for (int kx = 0; kx < KU; ++kx) {
+              const int ox = px - kx + p.pad;
+              const bool okx = ox >= 0 && ox < p.W;
+              ok[kx] = oky && okx;
+              v[kx] = ld4t<DY_BF16>(dy, (rowb + (okx ? ox : 0)) * C4 + cg);
+            }
+#pragma unroll
+            for (int kx = 0; kx < KU; ++kx) {
+              const float4 wv = reinterpret_cast<const float4*>(wl)[(ky * KU + kx) * C4 + cg];
+              if (ok[kx]) acc = f4fma(v[kx], wv, acc);
+            }
+          }
+        } else {
+          for (int ky = 0; ky < k; ++ky) {
+            const int oy = py - ky + p.pad;
+            if (oy < 0 || oy >= p.H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+              const int ox = px - kx + p.pad;
+              if (ox < 0 || ox >= p.W) continue;
+              acc = f4fma(ld4t<DY_BF16>(dy, ((b * p.H + oy) * p.W + ox) * C4 + cg), reinterpret_cast<const float4*>(wl)[(ky * k + kx) * C4 + cg], acc);
+            }
           }
         }
       }
@@ -713,7 +763,11 @@ extern "C" int mfnet_dwconv_fwd(const float* x, const float* w, const float* bia
   DwParams p;
   int rc = dw_check(&p, B, H, W, C, k, ext, "dwconv_fwd");
   if (rc) return rc;
-  hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(grid_for(B * H * W * C / 4)), dim3(256), (size_t)(k * k * C * 4), stream, x, w, bias, y, p);
+  const dim3 grid(grid_for(B * H * W * C / 4));
+  const size_t lds = (size_t)(k * k * C * 4);
+  if (k == 8) hipLaunchKernelGGL(dwconv_fwd_kernel<8>, grid, dim3(256), lds, stream, x, w, bias, y, p);
+  else if (k == 3) hipLaunchKernelGGL(dwconv_fwd_kernel<3>, grid, dim3(256), lds, stream, x, w, bias, y, p);
+  else hipLaunchKernelGGL(dwconv_fwd_kernel<0>, grid, dim3(256), lds, stream, x, w, bias, y, p);
   MF_LAUNCH_CHECK("dwconv_fwd");
   return MFNET_OK;
 }
@@ -723,8 +777,15 @@ extern "C" int mfnet_dwconv_bwd_data(const void* dy, int dy_dtype, const float* 
   DwParams p;
   int rc = dw_check(&p, B, H, W, C, k, ext, "dwconv_bwd_data");
   if (rc) return rc;
-  if (dy_dtype == MFNET_BF16) hipLaunchKernelGGL(dwconv_bwd_data_kernel<true>, dim3(grid_for(B * H * W * C / 4)), dim3(256), (size_t)(k * k * C * 4), stream, dy, dy_dtype, w, dx, p);
-  else hipLaunchKernelGGL(dwconv_bwd_data_kernel<false>, dim3(grid_for(B * H * W * C / 4)), dim3(256), (size_t)(k * k * C * 4), stream, dy, dy_dtype, w, dx, p);
+  const dim3 grid(grid_for(B * H * W * C / 4));
+  const size_t lds = (size_t)(k * k * C * 4);
+#define DW_BWD_DATA(BF) do {                                                                                              \
+    if (k == 8) hipLaunchKernelGGL((dwconv_bwd_data_kernel<BF, 8>), grid, dim3(256), lds, stream, dy, dy_dtype, w, dx, p);      \
+    else if (k == 3) hipLaunchKernelGGL((dwconv_bwd_data_kernel<BF, 3>), grid, dim3(256), lds, stream, dy, dy_dtype, w, dx, p); \
+    else hipLaunchKernelGGL((dwconv_bwd_data_kernel<BF, 0>), grid, dim3(256), lds, stream, dy, dy_dtype, w, dx, p);             \
+  } while (0)
+  if (dy_dtype == MFNET_BF16) DW_BWD_DATA(true); else DW_BWD_DATA(false);
+#undef DW_BWD_DATA
   MF_LAUNCH_CHECK("dwconv_bwd_data");
   return MFNET_OK;
 }

@@ -674,3 +674,32 @@ def test_bn_train_apply_equals_finalize_then_apply(rows, C, act):
     ref = torch.nn.functional.batch_norm(x.double(), None, None, gamma.double(), beta.double(), True, 0.1, 1e-5)
     if act == 0:
         assert (y_a.double() - ref).abs().max().item() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ depthwise conv
+@pytest.mark.parametrize("B,H,W,C,k,ext,bf", [(2, 8, 8, 64, 8, True, False), (2, 16, 12, 64, 8, True, True), (1, 32, 32, 64, 8, True, False),
+                                              (2, 16, 16, 64, 3, False, False), (1, 9, 7, 32, 3, False, True), (1, 10, 10, 16, 5, False, False)])
+def test_depthwise_conv_fwd_bwd_vs_float64(ops, B, H, W, C, k, ext, bf):
+    """depthwise k x k conv on channels-last maps (unetformer_mmsam.py:62-72 SeparableConvBN's first conv; ext = the reflected
+    bottom / right row of GlobalLocalAttention.pad_out, :192-196): forward, data gradient, weight and bias gradients against
+    F.conv2d(groups=C) in float64; k = 3 and 8 take the row-batched kernels, k = 5 the generic one."""
+    x = rnd(B, H, W, C, seed=1)
+    w = rnd(C, 1, k, k, seed=2) * 0.2
+    bias = rnd(C, seed=3)
+    dy = rnd(B, H, W, C, seed=4)
+    xd = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    bd = bias.double().requires_grad_(True)
+    pad = (k - 1) // 2
+    xin = F.pad(xd, (0, 1, 0, 1), mode="reflect") if ext else xd
+    ref = F.conv2d(xin, wd, bd, padding=pad, groups=C)[:, :, :H, :W]
+    dyd = (dy.bfloat16() if bf else dy).double().permute(0, 3, 1, 2)
+    ref.backward(dyd)
+    xc, wc = x.cuda(), w.cuda().reshape(C, k * k).contiguous()
+    y = ops.dwconv_fwd(xc, wc, bias.cuda(), B, H, W, k, ext)
+    assert rel_err(y.permute(0, 3, 1, 2), ref) < 1e-5
+    dyc = dy.cuda().bfloat16() if bf else dy.cuda()
+    dx, dw, db = ops.dwconv_bwd(dyc, xc, wc, B, H, W, k, ext, want_bias=True)
+    assert rel_err(dx.permute(0, 3, 1, 2), xd.grad) < 1e-5
+    assert rel_err(dw.materialize().view(C, 1, k, k), wd.grad) < 1e-5
+    assert rel_err(db.materialize(), bd.grad) < 1e-5
