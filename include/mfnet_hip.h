@@ -196,6 +196,16 @@ int mfnet_gemm_tn_bf16(const void* dy, int64_t ldy, const void* x, int64_t ldx, 
  * (adapter.py:13-14 D_fc1 / D_fc2 of Img_ / DSM_ and MLPx_ / MLPy_Adapter). bias_part (nullable): [splits][n_groups][N]. */
 int mfnet_gemm_tn_bf16_grouped(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t M, int64_t N, int64_t K,
                                float* out, int64_t ldo, int splits, int n_groups, float* bias_part, hipStream_t stream);
+/* 3x3 / stride 1 / zero-pad 1 convolution of a channels-last bf16 map as an implicit GEMM (no column tensor): x [B*H*W, C]
+ * (row stride ldx, C % 64 == 0), w [N, 9*C] with k = tap*C + c (tap = 3*ky + kx), out [B*H*W, N] bf16 or fp32: the 3x3 convs of
+ * the decoder and the neck (unetformer_mmsam.py:43-60 ConvBNReLU / ConvBN / Conv with kernel_size=3, image_encoder.py:112-118).
+ * The data gradient is the same call on dy with flipped, transposed weights [C, 9*N] (k = (8 - tap)*N + n);
+ * mfnet_gemm_tn_conv3x3 is the weight gradient out[n][tap*C + c] = sum_p dy[p][n] * x[p shifted by tap][c]
+ * (splits / partial tiles / bias_part as mfnet_gemm_tn_bf16 with M = B*H*W, K = 9*C). */
+int mfnet_conv3x3_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, int64_t B, int64_t H, int64_t W, int64_t C,
+                       int64_t N, void* out, int out_dtype, int64_t ldc, hipStream_t stream);
+int mfnet_gemm_tn_conv3x3(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t B, int64_t H, int64_t W, int64_t C,
+                          int64_t N, float* out, int64_t ldo, int splits, float* bias_part, hipStream_t stream);
 int64_t mfnet_gemm_tn_splits(int64_t M, int64_t N, int64_t K);
 int mfnet_reduce_splits(const float* partial, float* out, int64_t n, int splits, float scale, int accumulate, hipStream_t stream);
 

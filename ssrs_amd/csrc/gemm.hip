@@ -21,6 +21,7 @@
 // remapped so each XCD walks a contiguous run of tiles (shared A panel in its private L2).
 #include "common.h"
 #include "gemm_params.h"
+#include <string.h>
 
 #define BM 128
 #define BN 128
@@ -40,7 +41,13 @@ __device__ __forceinline__ int swz_w(int row) { return (((row >> 4) & 3) << 1) |
 // ACT = GemmParams::act. The activations
 // and low-rank epilogues are compiled into separate instantiations: one kernel with everything is ~100 KB of
 // code, more than the 64 KB instruction cache a CU pair shares.
-template <int ACT, bool LORA>
+// CONV: implicit-GEMM 3x3 convolution (stride 1, zero padding 1) of a channels-last map: K-tile kt is channel block kt % conv_cb
+// of tap kt / conv_cb, and the A rows of that tile are the map rows of the pixels shifted by the tap - fetched by the same
+// global_load_lds as a plain A tile, from a row of zeros where the shifted pixel falls outside the image. No column tensor
+// (the 9x copy im2col3x3 wrote and this kernel, the weight-gradient product and col2im3x3 read back) exists any more.
+__device__ __attribute__((aligned(128))) unsigned char g_zero_row[128];     // (zero-initialised device memory, never written)
+
+template <int ACT, bool LORA, bool CONV = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (BM + BN) * BK * 2];  // 64 KiB
   const int tid = threadIdx.x;
@@ -85,6 +92,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
   const int nt = (p.K + BK - 1) / BK;
   const bool half_tail = (p.K & (BK - 1)) != 0;
   int a_tail[4], w_tail[4];
+  int ay[4], ax[4];                  // CONV: image coordinates of this lane's four A rows
+  const bf16_t* zsrc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = wave * 32 + i * 8 + srow;
@@ -99,13 +108,27 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     w_src[i] = Wg + (int64_t)gn * p.ldw + (cw << 3);
     a_tail[i] = (half_tail && ca >= 4) ? -32 : 0;
     w_tail[i] = (half_tail && cw >= 4) ? -32 : 0;
+    if (CONV) {
+      const int pix = gm % (p.conv_H * p.conv_W);
+      ay[i] = pix / p.conv_W; ax[i] = pix - ay[i] * p.conv_W;
+      zsrc[i] = reinterpret_cast<const bf16_t*>(g_zero_row) + (ca << 3);
+    }
   }
   auto stage = [&](int kt, int buf) {
     unsigned char* base = lds + buf * ((BM + BN) * BK * 2);
     const bool last = kt == nt - 1;
+    int dyy = 0, dxx = 0;
+    int64_t aoff = (int64_t)kt * BK;
+    if (CONV) {
+      const int tap = kt / p.conv_cb, t3 = tap / 3;
+      dyy = t3 - 1; dxx = tap - 3 * t3 - 1;
+      aoff = (int64_t)(dyy * p.conv_W + dxx) * p.lda + (kt - tap * p.conv_cb) * BK;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + kt * BK + (last ? a_tail[i] : 0)),
+      const bf16_t* asrc = a_src[i] + aoff + (last ? a_tail[i] : 0);
+      if (CONV && !((unsigned)(ay[i] + dyy) < (unsigned)p.conv_H && (unsigned)(ax[i] + dxx) < (unsigned)p.conv_W)) asrc = zsrc[i];
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)asrc,
                                        (lds_ptr_t)(base + (wave * 4 + i) * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[i] + kt * BK + (last ? w_tail[i] : 0)),
                                        (lds_ptr_t)(base + BM * BK * 2 + (wave * 4 + i) * 1024), 16, 0, 0);
@@ -426,6 +449,7 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int
   MF_CHECK_ARG(nwg < (1ll << 31), "gemm_bf16: too many tiles");
   p.k_splits = k_splits;
   p.w_group_stride = w_group_stride; p.bias_group_stride = bias_group_stride;
+  p.conv_H = p.conv_W = p.conv_cb = 0;
 #ifdef GEMM_STAMPS
   p.stamps = g_stamps; p.stagger = g_stagger;
 #endif
@@ -441,6 +465,34 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, int
 #undef MF_GEMM_CASE
 #undef MF_GEMM_LAUNCH
   MF_LAUNCH_CHECK("gemm_bf16");
+  return MFNET_OK;
+}
+
+// 3x3 / stride 1 / zero-pad 1 convolution of a channels-last bf16 map as an implicit GEMM: x [B*H*W, C] (row stride ldx), w [N, 9*C]
+// with k = tap*C + c (tap = 3*ky + kx), out [B*H*W, N] bf16 or fp32. The data gradient is the same call on dy with the weights
+// flipped and transposed ([C, 9*N], k = tap'*N + n, tap' = 8 - tap).
+extern "C" int mfnet_conv3x3_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, int64_t B, int64_t H, int64_t W, int64_t C,
+                                  int64_t N, void* out, int out_dtype, int64_t ldc, hipStream_t stream) {
+  MF_CHECK_ARG(x && w && out, "conv3x3_bf16: null operand");
+  MF_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 64 == 0, "conv3x3_bf16: bad geometry (channels must be a multiple of 64, got %lld)", (long long)C);
+  MF_CHECK_ARG(N > 0 && N % 16 == 0, "conv3x3_bf16: N=%lld must be a multiple of 16", (long long)N);
+  MF_CHECK_ARG(ldx >= C && ldx % 8 == 0 && ldw >= 9 * C && ldw % 8 == 0 && ldc >= N && ldc % 8 == 0, "conv3x3_bf16: bad leading dimensions");
+  MF_CHECK_ARG(((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) % 16 == 0, "conv3x3_bf16: operands must be 16-byte aligned");
+  MF_CHECK_ARG(out_dtype == MFNET_BF16 || out_dtype == MFNET_F32, "conv3x3_bf16: bad out dtype");
+  const int64_t M = B * H * W;
+  MF_CHECK_ARG(M < (1ll << 31) && H * W < (1ll << 31) && H < (1 << 20) && W < (1 << 20), "conv3x3_bf16: map too large");
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = (const bf16_t*)x; p.lda = ldx; p.W = (const bf16_t*)w; p.ldw = ldw;
+  p.M = (int)M; p.N = (int)N; p.K = (int)(9 * C);
+  p.n_groups = 1; p.out = out; p.out_dtype = out_dtype; p.ldc = ldc;
+  p.tiles_m = (int)ceil_div64(M, BM); p.tiles_n = (int)ceil_div64(N, BN);
+  p.k_splits = 1;
+  p.conv_H = (int)H; p.conv_W = (int)W; p.conv_cb = (int)(C / 64);
+  const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+  MF_CHECK_ARG(nwg < (1ll << 31), "conv3x3_bf16: too many tiles");
+  hipLaunchKernelGGL((gemm_bf16_kernel<0, false, true>), dim3((unsigned)nwg, 1), dim3(256), 0, stream, p);
+  MF_LAUNCH_CHECK("conv3x3_bf16");
   return MFNET_OK;
 }
 

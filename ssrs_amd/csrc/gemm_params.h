@@ -20,6 +20,8 @@ struct GemmParams {
   int tiles_m, tiles_n;
   int k_splits;                         // > 1: blockIdx.y owns a K range and stores its fp32 partial into slice blockIdx.y of out
   int64_t w_group_stride, bias_group_stride;   // != 0: W / bias of row group g start g * stride elements further (per-modality layers)
+  int conv_H, conv_W, conv_cb;          // conv_cb != 0 (gemm.hip only): A is a [B*conv_H*conv_W, 64*conv_cb] channels-last map and the product
+                                        // is its 3x3 / pad 1 convolution, K = 9 * 64 * conv_cb with k = tap * C + c (implicit im2col)
 #ifdef GEMM_STAMPS
   unsigned long long* stamps;
   int stagger;

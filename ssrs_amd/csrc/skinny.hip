@@ -334,9 +334,13 @@ extern "C" int mfnet_skinny_tn(const void* Y, int64_t ldy, const float* U, int64
 // has no barrier; the next step's global loads are in flight while the current one multiplies.
 // The row range is cut into `splits`; split s stores its partial tile into out + s*N*ldo (mfnet_reduce_splits
 // sums them), exactly like the split-K mode of mfnet_gemm_bf16.
+// CONV: X is a channels-last map [B*cH*cW, cC] and the k index runs over (tap, channel) of its 3x3 / pad 1 neighbourhood
+// (k = tap*cC + c): the weight gradient of a 3x3 convolution without the im2col tensor - the X rows of a k block are the map
+// rows of the pixels shifted by the block's tap, zero where that leaves the image.
+template <bool CONV>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ DY, int64_t ldy, const bf16_t* __restrict__ X, int64_t ldx,
                                                       int64_t M, int N, int K, int64_t rows_per_split, float* __restrict__ out, int64_t ldo,
-                                                      int splits, float* __restrict__ bias_part) {
+                                                      int splits, float* __restrict__ bias_part, int cH, int cW, int cC) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[4][2][32 * 128];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
@@ -371,13 +375,34 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   u32x4_t av[4], bv[4];
+  int py[4], px[4], dyy = 0, dxx = 0, xcol = bcol;                  // CONV: image coordinates of the lane's rows, this k block's tap
+  if (CONV) {
+    const int tap = k0 / cC, t3 = tap / 3;
+    dyy = t3 - 1; dxx = tap - 3 * t3 - 1;
+    xcol = k0 - tap * cC + sch * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pix = (int)((r_begin + srow + 8 * i) % ((int64_t)cH * cW));
+      py[i] = pix / cW; px[i] = pix - py[i] * cW;
+    }
+  }
+  const int adv_y = CONV ? 32 / cW : 0, adv_x = CONV ? 32 % cW : 0;
   auto issue = [&](int64_t m0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int64_t m = m0 + srow + 8 * i;
       const int64_t mc = m < r_end ? m : r_end - 1;
       av[i] = *reinterpret_cast<const u32x4_t*>(DY + mc * ldy + acol);
-      bv[i] = *reinterpret_cast<const u32x4_t*>(X + mc * ldx + bcol);
+      if (CONV) {
+        const bool ok = m < r_end && (unsigned)(py[i] + dyy) < (unsigned)cH && (unsigned)(px[i] + dxx) < (unsigned)cW;
+        bv[i] = *reinterpret_cast<const u32x4_t*>(X + (ok ? m + dyy * cW + dxx : mc) * ldx + xcol);
+        if (!ok) bv[i] = (u32x4_t){0u, 0u, 0u, 0u};
+        px[i] += adv_x; py[i] += adv_y;                            // the next step's rows are 32 pixels on
+        if (px[i] >= cW) { px[i] -= cW; ++py[i]; }
+        while (py[i] >= cH) py[i] -= cH;
+      } else {
+        bv[i] = *reinterpret_cast<const u32x4_t*>(X + mc * ldx + bcol);
+      }
       if (m >= r_end) av[i] = (u32x4_t){0u, 0u, 0u, 0u};          // rows past the split contribute nothing
     }
   };
@@ -449,17 +474,19 @@ extern "C" int64_t mfnet_gemm_tn_splits(int64_t M, int64_t N, int64_t K) {
 }
 
 static int gemm_tn_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t M, int64_t N, int64_t K,
-                          float* out, int64_t ldo, int splits, int n_groups, float* bias_part, hipStream_t stream) {
+                          float* out, int64_t ldo, int splits, int n_groups, float* bias_part, hipStream_t stream,
+                          int cH = 0, int cW = 0, int cC = 0) {
   MF_CHECK_ARG(dy && x && out, "gemm_tn: null pointer");
   MF_CHECK_ARG(n_groups >= 1 && (int64_t)n_groups * splits <= 65535, "gemm_tn: bad group count");
   MF_CHECK_ARG(M > 0 && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0, "gemm_tn: N=%lld and K=%lld must be multiples of 8", (long long)N, (long long)K);
-  MF_CHECK_ARG(ldy % 8 == 0 && ldx % 8 == 0 && ldy >= N && ldx >= K && ldo >= K, "gemm_tn: bad leading dimensions");
+  MF_CHECK_ARG(ldy % 8 == 0 && ldx % 8 == 0 && ldy >= N && ldx >= (cC ? cC : K) && ldo >= K, "gemm_tn: bad leading dimensions");
   MF_CHECK_ARG(((uintptr_t)dy | (uintptr_t)x) % 16 == 0, "gemm_tn: operands must be 16-byte aligned");
   MF_CHECK_ARG(splits >= 1 && splits <= 65535 && N < (1ll << 31) && K < (1ll << 31), "gemm_tn: bad splits / shape");
   int64_t rps = ceil_div64(ceil_div64(M, splits), 32) * 32;
   dim3 grid((unsigned)ceil_div64(K, 256), (unsigned)ceil_div64(N, 64), (unsigned)(splits * n_groups));
   MF_CHECK_ARG(grid.y <= 65535, "gemm_tn: N too large");
-  hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, stream, (const bf16_t*)dy, ldy, (const bf16_t*)x, ldx, M, (int)N, (int)K, rps, out, ldo, splits, bias_part);
+  if (cC) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, stream, (const bf16_t*)dy, ldy, (const bf16_t*)x, ldx, M, (int)N, (int)K, rps, out, ldo, splits, bias_part, cH, cW, cC);
+  else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, stream, (const bf16_t*)dy, ldy, (const bf16_t*)x, ldx, M, (int)N, (int)K, rps, out, ldo, splits, bias_part, 0, 0, 0);
   MF_LAUNCH_CHECK("gemm_tn");
   return MFNET_OK;
 }
@@ -467,6 +494,16 @@ static int gemm_tn_launch(const void* dy, int64_t ldy, const void* x, int64_t ld
 extern "C" int mfnet_gemm_tn_bf16(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t M, int64_t N, int64_t K,
                                   float* out, int64_t ldo, int splits, float* bias_part, hipStream_t stream) {
   return gemm_tn_launch(dy, ldy, x, ldx, M, N, K, out, ldo, splits, 1, bias_part, stream);
+}
+
+// Weight gradient of a 3x3 / pad 1 convolution without the column tensor: out[n][tap*C + c] = sum over pixels p of
+// dy[p][n] * x[p shifted by tap][c] (zero outside the image); x [B*H*W, C] channels-last bf16, C % 64 == 0. Splits, partial tiles
+// and bias_part as mfnet_gemm_tn_bf16 with M = B*H*W, K = 9*C.
+extern "C" int mfnet_gemm_tn_conv3x3(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t B, int64_t H, int64_t W, int64_t C,
+                                     int64_t N, float* out, int64_t ldo, int splits, float* bias_part, hipStream_t stream) {
+  MF_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 64 == 0 && H < (1 << 20) && W < (1 << 20) && H * W < (1ll << 31),
+               "gemm_tn_conv3x3: bad geometry (channels must be a multiple of 64, got %lld)", (long long)C);
+  return gemm_tn_launch(dy, ldy, x, ldx, B * H * W, N, 9 * C, out, ldo, splits, 1, bias_part, stream, (int)H, (int)W, (int)C);
 }
 
 // n_groups independent products in one launch: group g takes rows [g*M, (g+1)*M) of dy and x (M = rows PER GROUP) and

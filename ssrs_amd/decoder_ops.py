@@ -65,16 +65,30 @@ def _bn_bwd(dy, x, mean, rstd, bn, training, act=ACT_NONE, dx_dtype=F32, chan_sc
     return ops.bn_backward(dy, x, mean, rstd, bn.weight, bn.bias, training, act, chan_scale, rpi, dx_dtype)
 
 
+def _wb_w3flipT(w):  # -> bf16 [I, 9*O], k = (8 - tap)*O + o: the weights of the data gradient as a 3x3 convolution of dy
+    w = w.detach()
+    O, I = w.shape[:2]
+    src = w.reshape(O, I, 9)
+    return derived(("w3fT", w.data_ptr()), (I, 9 * O), BF, lambda t: [(t.view(I, 9, O)[:, 8 - k], src[:, :, k].t()) for k in range(9)], device=w.device)
+
+
 def _conv3_fwd(x_bf, w, B, H, W):
+    """-> (conv output fp32 [M, O], what the backward needs). Channels that are multiples of 64 (every 3x3 conv of MFNet) take the
+    implicit-GEMM kernel and keep only x; others go through the column tensor."""
+    if x_bf.shape[1] % 64 == 0 and w.shape[0] % 64 == 0:
+        return ops.conv3x3(x_bf, _wb_w3(w), B, H, W), x_bf
     cols = ops.im2col3x3(x_bf, B, H, W)
     return ops.gemm(cols, _wb_w3(w), out_dtype=F32), cols
 
 
-def _conv3_bwd(dy_bf, cols, w, B, H, W):
+def _conv3_bwd(dy_bf, saved, w, B, H, W):
     """-> (dx fp32 [M, I], dW like w)."""
+    if saved.shape[1] == w.shape[1]:                     # the input map itself: implicit-GEMM path
+        dx = ops.conv3x3(dy_bf, _wb_w3flipT(w), B, H, W)
+        return dx, _w3_grad(ops.conv3x3_wgrad(dy_bf, saved, B, H, W), w)
     dcols = ops.gemm(dy_bf, _wb_w3T(w))
     dx = ops.col2im3x3(dcols, B, H, W, w.shape[1])
-    return dx, _w3_grad(ops.gemm_tn(dy_bf, cols, lazy=True), w)
+    return dx, _w3_grad(ops.gemm_tn(dy_bf, saved, lazy=True), w)
 
 
 def _w2(w):          # 1x1 conv weight [O, I, 1, 1] -> [O, I]

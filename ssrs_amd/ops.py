@@ -391,6 +391,36 @@ def col2im3x3(dcols, G, H, W, C):
     return dx
 
 
+def conv3x3(x, w, G, H, W, out_dtype=torch.float32):
+    """3x3 / pad 1 convolution as an implicit GEMM: x [G*H*W, C] bf16 channels-last rows (C % 64 == 0), w [N, 9*C] bf16 with
+    k = tap*C + c -> [G*H*W, N]. The data gradient is the same call on dy with the flipped, transposed weights."""
+    _chk(x, w)
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 2 and w.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1
+    C, N = x.shape[1], w.shape[0]
+    assert x.shape[0] == G * H * W and w.shape[1] == 9 * C
+    out = torch.empty((x.shape[0], N), dtype=out_dtype, device=x.device)
+    call("mfnet_conv3x3_bf16", x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), G, H, W, C, N, out.data_ptr(), _dt(out), N, _stream(x))
+    return out
+
+
+def conv3x3_wgrad(dy, x, G, H, W, want_bias=False):
+    """weight gradient of conv3x3: [N, 9*C] fp32 (k = tap*C + c) as a SplitSum over the row splits (a plain tensor when there is
+    one split); dy [G*H*W, N] bf16, x [G*H*W, C] bf16, C % 64 == 0. want_bias: (dW, db) with db = column sums of dy."""
+    _chk(dy, x)
+    assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.stride(-1) == 1 and x.stride(-1) == 1
+    M, N = dy.shape
+    C = x.shape[1]
+    assert x.shape[0] == M == G * H * W
+    K = 9 * C
+    splits = int(_lib.lib().mfnet_gemm_tn_splits(M, N, K))
+    part = torch.empty((splits, N, K), dtype=torch.float32, device=dy.device)
+    bpart = torch.empty((splits, N), dtype=torch.float32, device=dy.device) if want_bias else None
+    call("mfnet_gemm_tn_conv3x3", dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), G, H, W, C, N, part.data_ptr(), K, splits,
+         bpart.data_ptr() if want_bias else None, _stream(dy))
+    dW = part[0] if splits == 1 else SplitSum(part)
+    return (dW, SplitSum(bpart)) if want_bias else dW
+
+
 def lora_mix_fwd(a, wx, wy):
     _chk(a, wx, wy)
     M, r = a.shape

@@ -308,8 +308,10 @@ class _Neck(torch.autograd.Function):
         hb = ops.cast(h.reshape(M, D).contiguous(), BF)
         n1 = ops.gemm(hb, w_bf16(neck[0].weight), out_dtype=torch.float32)
         l1, m1, r1 = ops.layernorm_fwd(n1, neck[1].weight, neck[1].bias, neck[1].eps)
-        cols = ops.im2col3x3(l1, G, Sh, Sw)
-        n2 = ops.gemm(cols, _neck3x3_w(neck[2].weight), out_dtype=torch.float32)
+        if C % 64 == 0:                  # implicit-GEMM 3x3 conv: no column tensor
+            n2 = ops.conv3x3(l1, _neck3x3_w(neck[2].weight), G, Sh, Sw)
+        else:
+            n2 = ops.gemm(ops.im2col3x3(l1, G, Sh, Sw), _neck3x3_w(neck[2].weight), out_dtype=torch.float32)
         out, m3, r3 = ops.layernorm_fwd(n2, neck[3].weight, neck[3].bias, neck[3].eps, out_dtype=torch.float32)
         ctx.save_for_backward(n1, m1, r1, n2, m3, r3)
         ctx.enc, ctx.shape = enc, (G, Sh, Sw, D, C)
@@ -322,8 +324,10 @@ class _Neck(torch.autograd.Function):
         neck = ctx.enc.neck
         M = G * Sh * Sw
         _, dn2 = ops.layernorm_bwd(dout.reshape(M, C).contiguous(), n2, m3, r3, neck[3].weight, want_f32=False, want_bf16=True)
-        dcols = ops.gemm(dn2, _neck3x3_wT(neck[2].weight))
-        dl1 = ops.col2im3x3(dcols, G, Sh, Sw, C)
+        if C % 64 == 0:
+            dl1 = ops.conv3x3(dn2, _neck3x3_wflipT(neck[2].weight), G, Sh, Sw)
+        else:
+            dl1 = ops.col2im3x3(ops.gemm(dn2, _neck3x3_wT(neck[2].weight)), G, Sh, Sw, C)
         _, dn1 = ops.layernorm_bwd(dl1, n1, m1, r1, neck[1].weight, want_f32=False, want_bf16=True)
         dh = ops.gemm(dn1, wT_bf16(neck[0].weight), out_dtype=torch.float32)
         return dh.view(G, Sh, Sw, D), None
@@ -331,6 +335,10 @@ class _Neck(torch.autograd.Function):
 
 def _neck3x3_w(w):     # [O, I, 3, 3] -> [O, 9*I] with k = tap*I + c  (im2col3x3 order)
     return _cached(("n3",), (w,), lambda: ops.cast(w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous(), BF))
+
+
+def _neck3x3_wflipT(w):   # [O, I, 3, 3] -> [I, 9*O] with k = (8 - tap)*O + o: the data gradient as a 3x3 conv of dy
+    return _cached(("n3fT",), (w,), lambda: ops.cast(w.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], -1).contiguous(), BF))
 
 
 def _neck3x3_wT(w):

@@ -703,3 +703,45 @@ def test_depthwise_conv_fwd_bwd_vs_float64(ops, B, H, W, C, k, ext, bf):
     assert rel_err(dx.permute(0, 3, 1, 2), xd.grad) < 1e-5
     assert rel_err(dw.materialize().view(C, 1, k, k), wd.grad) < 1e-5
     assert rel_err(db.materialize(), bd.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ implicit-GEMM 3x3 convolution
+@pytest.mark.parametrize("G,H,W,C,N", [(2, 16, 16, 64, 64), (1, 8, 8, 64, 64), (3, 12, 20, 128, 48), (2, 16, 16, 256, 256), (1, 5, 7, 64, 16),
+                                       (16, 64, 64, 64, 64)])
+def test_conv3x3_implicit_gemm_fwd_dgrad_wgrad(ops, G, H, W, C, N):
+    """3x3 / pad 1 convs of the decoder and the neck without a column tensor (unetformer_mmsam.py:43-60, image_encoder.py:112-118):
+    forward, data gradient (same kernel, flipped + transposed weights) and weight gradient against F.conv2d in float64 on the
+    bf16-rounded operands; partial tiles (M % 128, N < 128), several k blocks per tap (C = 128, 256) and image borders included."""
+    x = bf16r(rnd(G, H, W, C, seed=1))
+    w = bf16r(rnd(N, C, 3, 3, seed=2) * 0.1)
+    dy = bf16r(rnd(G, H, W, N, seed=3))
+    xd = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    ref = F.conv2d(xd, wd, padding=1)
+    ref.backward(dy.double().permute(0, 3, 1, 2))
+    xb = x.cuda().bfloat16().view(-1, C)
+    wb = w.cuda().permute(0, 2, 3, 1).reshape(N, 9 * C).bfloat16().contiguous()
+    y = ops.conv3x3(xb, wb, G, H, W)
+    assert rel_err(y.view(G, H, W, N).permute(0, 3, 1, 2), ref) < 1e-5
+    yb = ops.conv3x3(xb, wb, G, H, W, out_dtype=torch.bfloat16)
+    assert rel_err(yb.float().view(G, H, W, N).permute(0, 3, 1, 2), ref) < 5e-3
+    dyb = dy.cuda().bfloat16().view(-1, N)
+    wT = w.cuda().flip(2, 3).permute(1, 2, 3, 0).reshape(C, 9 * N).bfloat16().contiguous()
+    dx = ops.conv3x3(dyb, wT, G, H, W) if N % 64 == 0 else None
+    if dx is not None:
+        assert rel_err(dx.view(G, H, W, C).permute(0, 3, 1, 2), xd.grad) < 1e-5
+    dW, db = ops.conv3x3_wgrad(dyb, xb, G, H, W, want_bias=True)
+    dW = dW.materialize() if isinstance(dW, ops.SplitSum) else dW
+    assert rel_err(dW.view(N, 3, 3, C).permute(0, 3, 1, 2), wd.grad) < 1e-4
+    assert rel_err(db.materialize(), dy.double().sum((0, 1, 2))) < 1e-5
+    # the column-tensor path it replaces gives the same numbers
+    cols = ops.im2col3x3(xb.contiguous(), G, H, W)
+    assert rel_err(ops.gemm(cols, wb, out_dtype=torch.float32), y) < 1e-6
+
+
+def test_conv3x3_rejects_bad_geometry(ops):
+    from ssrs_amd._lib import MfnetError
+    x = torch.zeros(64, 32, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(16, 9 * 32, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(MfnetError):
+        ops.conv3x3(x, w, 1, 8, 8)                     # channels not a multiple of 64
