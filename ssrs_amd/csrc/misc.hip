@@ -1,6 +1,8 @@
 // Small HBM-bound data-movement kernels of the encoder path: dtype casts, patch-embed im2col,
 // 3x3 im2col / col2im for the neck conv, the LoRA cross-modal mix (loralib/layers.py:159-160).
 #include "common.h"
+#include <algorithm>
+#include <vector>
 #include <string.h>
 
 // ------------------------------------------------------------------------------------------- cast
@@ -308,12 +310,25 @@ extern "C" int mfnet_gather_segments(const int64_t* desc, int n, int dst_dtype, 
   MF_CHECK_ARG(n >= 0 && (n == 0 || desc), "gather_segments: bad args");
   MF_CHECK_ARG(dst_dtype == MFNET_F32 || (dst_dtype == MFNET_BF16 && !accumulate), "gather_segments: accumulate needs an fp32 destination");
   const int mode = dst_dtype == MFNET_BF16 ? 2 : (accumulate ? 1 : 0);
+  // Segments are independent; a launch's grid is sized by its largest one, so they go out sorted by work: the few big ones
+  // (FPN / conv weight gradients with their partial tiles) share the first launch and the hundreds of small ones run in launches
+  // of a few workgroups each (unsorted, every launch carried one big segment and 47 columns of idle workgroups).
+  std::vector<int> order(n);
+  std::vector<int64_t> work(n);
+  for (int i = 0; i < n; ++i) {
+    const int64_t* d = desc + (int64_t)i * 17;
+    int64_t tot = 1;
+    for (int k = 0; k < 4; ++k) tot *= (d[2 + k] >= 1 && d[2 + k] < (1ll << 31)) ? d[2 + k] : 1;     // (validated below)
+    order[i] = i;
+    work[i] = tot * (d[14] < 1 ? 1 : (d[14] < 16 ? d[14] : 16));
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return work[a] > work[b]; });
   for (int base = 0; base < n; base += SEG_MAX) {
     const int cnt = n - base < SEG_MAX ? n - base : SEG_MAX;
     GatherParams p;
     int64_t nmax = 0;
     for (int i = 0; i < SEG_MAX; ++i) {
-      const int64_t* d = desc + (int64_t)(base + (i < cnt ? i : 0)) * 17;      // unused slots repeat a valid one
+      const int64_t* d = desc + (int64_t)order[base + (i < cnt ? i : 0)] * 17;      // unused slots repeat a valid one
       GatherSeg& s = p.seg[i];
       s.src = (const float*)(uintptr_t)d[0]; s.dst = (void*)(uintptr_t)d[1];
       MF_CHECK_ARG(s.src && s.dst, "gather_segments: null pointer in segment %d", base + i);

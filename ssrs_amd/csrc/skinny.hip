@@ -341,20 +341,28 @@ template <bool CONV>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ DY, int64_t ldy, const bf16_t* __restrict__ X, int64_t ldx,
                                                       int64_t M, int N, int K, int64_t rows_per_split, float* __restrict__ out, int64_t ldo,
                                                       int splits, float* __restrict__ bias_part, int cH, int cW, int cC) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[4][2][32 * 128];
+  // staging: [wave][dy | x image][32 rows x 128 B]; after the row loop the same bytes carry the 4 -> 1 reduction of the waves'
+  // accumulators (two 20-KB slots: 16 weight tiles + the bias tile of one wave)
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * 20 * 1024];
+  unsigned char (*lds)[2][32 * 128] = reinterpret_cast<unsigned char (*)[2][32 * 128]>(lds_raw);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int n0 = blockIdx.y * 64;
-  const int k0 = (blockIdx.x * 4 + wave) * 64;
-  if (k0 >= K) return;
+  const int k0 = blockIdx.x * 64;
   // blockIdx.z = split * n_groups + group: group g owns rows [g*M, (g+1)*M) of both operands; partial tile (split, group)
   const int n_groups = gridDim.z / splits;
   const int sp = blockIdx.z / n_groups, gz = blockIdx.z - sp * n_groups;
   DY += (int64_t)gz * M * ldy;
   X += (int64_t)gz * M * ldx;
-  const int64_t r_begin = (int64_t)sp * rows_per_split;
-  int64_t r_end = r_begin + rows_per_split;
-  if (r_end > M) r_end = M;
+  // the workgroup owns one 64 x 64 output tile over the split's rows; its four waves take a quarter of the rows each and their
+  // accumulators are summed through LDS in a fixed order - a quarter of the partial tiles (and of their traffic in the kernel
+  // that sums them) for the same number of waves in flight as one wave per (tile, split)
+  const int64_t s_begin = (int64_t)sp * rows_per_split;
+  const int64_t s_end = s_begin + rows_per_split < M ? s_begin + rows_per_split : M;
+  const int64_t rpw = (rows_per_split + 127) / 128 * 32;
+  int64_t r_begin = s_begin + wave * rpw;
+  if (r_begin > s_end) r_begin = s_end;
+  const int64_t r_end = r_begin + rpw < s_end ? r_begin + rpw : s_end;
   out += (int64_t)blockIdx.z * N * ldo;
   // bias gradient = column sums of dy over the same rows: the wave that owns k-tile 0 multiplies its dy fragments by a
   // fragment of ones as well (4 more MFMAs per step) and writes the partial row [N] of this (split, group)
@@ -438,6 +446,38 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
       for (int a = 0; a < 4; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], ones, accb[a], 0, 0, 0);
     }
   }
+  // ---- waves 2, 3 -> slots 0, 1; waves 0, 1 add; wave 1 -> slot 0; wave 0 adds and stores
+  auto put = [&](int slot) {
+    float4* d = reinterpret_cast<float4*>(lds_raw + slot * 20 * 1024) + lane;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) d[(a * 4 + b) * 64] = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+      d[(16 + a) * 64] = make_float4(accb[a][0], accb[a][1], accb[a][2], accb[a][3]);
+    }
+  };
+  auto take = [&](int slot) {
+    const float4* d = reinterpret_cast<const float4*>(lds_raw + slot * 20 * 1024) + lane;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float4 v = d[(a * 4 + b) * 64];
+        acc[a][b][0] += v.x; acc[a][b][1] += v.y; acc[a][b][2] += v.z; acc[a][b][3] += v.w;
+      }
+      const float4 v = d[(16 + a) * 64];
+      accb[a][0] += v.x; accb[a][1] += v.y; accb[a][2] += v.z; accb[a][3] += v.w;
+    }
+  };
+  __syncthreads();                       // every wave is done with its staging images
+  if (wave >= 2) put(wave - 2);
+  __syncthreads();
+  if (wave < 2) take(wave);
+  __syncthreads();
+  if (wave == 1) put(0);
+  __syncthreads();
+  if (wave != 0) return;
+  take(0);
   if (want_b && fr == 0) {
     float* bo = bias_part + (int64_t)blockIdx.z * N;
 #pragma unroll
@@ -465,9 +505,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
 
 extern "C" int64_t mfnet_gemm_tn_splits(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 1;
-  const int64_t tiles = ceil_div64(N, 64) * ceil_div64(K, 256);
+  const int64_t tiles = ceil_div64(N, 64) * ceil_div64(K, 64);   // one 4-wave workgroup per tile and split
   int64_t s = ceil_div64(768, tiles);                  // ~3 workgroups per CU
-  const int64_t smax = ceil_div64(M, 256);             // at least 8 steps of 32 rows per split (partials cost traffic too)
+  const int64_t smax = ceil_div64(M, 1024);            // at least 8 steps of 32 rows per wave (partials cost traffic too)
   if (s > smax) s = smax;
   if (s > 256) s = 256;
   return s < 1 ? 1 : s;
@@ -483,7 +523,7 @@ static int gemm_tn_launch(const void* dy, int64_t ldy, const void* x, int64_t ld
   MF_CHECK_ARG(((uintptr_t)dy | (uintptr_t)x) % 16 == 0, "gemm_tn: operands must be 16-byte aligned");
   MF_CHECK_ARG(splits >= 1 && splits <= 65535 && N < (1ll << 31) && K < (1ll << 31), "gemm_tn: bad splits / shape");
   int64_t rps = ceil_div64(ceil_div64(M, splits), 32) * 32;
-  dim3 grid((unsigned)ceil_div64(K, 256), (unsigned)ceil_div64(N, 64), (unsigned)(splits * n_groups));
+  dim3 grid((unsigned)ceil_div64(K, 64), (unsigned)ceil_div64(N, 64), (unsigned)(splits * n_groups));
   MF_CHECK_ARG(grid.y <= 65535, "gemm_tn: N too large");
   if (cC) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, stream, (const bf16_t*)dy, ldy, (const bf16_t*)x, ldx, M, (int)N, (int)K, rps, out, ldo, splits, bias_part, cH, cW, cC);
   else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, stream, (const bf16_t*)dy, ldy, (const bf16_t*)x, ldx, M, (int)N, (int)K, rps, out, ldo, splits, bias_part, 0, 0, 0);
