@@ -155,6 +155,17 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
           acc[f][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[f], x[mi], acc[f][mi], 0, 0, 0);
       }
     };
+    // the 4 + NF reads of the next k-step are woven between the remaining 4 * (NF - 1) MFMAs of this one (PER MFMAs, then a read):
+    // issued in one burst, the 8 waves' reads queue at the LDS together and the MFMAs behind them in program order wait
+    auto weave = [&]() {
+      constexpr int NR = 4 + NF, NM = 4 * (NF - 1), PER = NM / NR > 0 ? NM / NR : 1;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NM - PER * NR > 0 ? NM - PER * NR : 0, 0);
+    };
     // tile 0 landed: at most the younger tiles of this wave outstanding
     if (nt >= C::STAGES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PPW * (C::STAGES - 1)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -170,8 +181,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
       mm(xa, wa, 0, 1);
       __builtin_amdgcn_sched_barrier(0);
       rd(base, 1, xb, wb);
-      __builtin_amdgcn_sched_barrier(0);
       mm(xa, wa, 1, NF);
+      weave();
       __builtin_amdgcn_sched_barrier(0);
       // tile t + 1 landed (tiles t + 2 .. t + STAGES - 1 may still be in flight) and this wave's reads of tile t returned
 #ifdef GEMM_NOWAIT      // diagnostic (wrong results): tiles are fetched but never waited for
@@ -187,15 +198,16 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
       mm(xb, wb, 0, 1);
       __builtin_amdgcn_sched_barrier(0);
       rd(lds + ((t + 1) % C::STAGES) * C::STAGE_BYTES, 0, xa, wa);
-      __builtin_amdgcn_sched_barrier(0);
       mm(xb, wb, 1, NF);
+      weave();
       __builtin_amdgcn_sched_barrier(0);
     }
     mm(xa, wa, 0, 1);
     __builtin_amdgcn_sched_barrier(0);
     rd(lds + ((nt - 1) % C::STAGES) * C::STAGE_BYTES, 1, xb, wb);
-    __builtin_amdgcn_sched_barrier(0);
     mm(xa, wa, 1, NF);
+    weave();
+    __builtin_amdgcn_sched_barrier(0);
     mm(xb, wb, 0, NF);
   } else {
 #pragma unroll
