@@ -94,6 +94,29 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIn* __restrict__ x, 
 // version read A from global per row: 24 KB per 3 KB row, 200 MB of L2 traffic per launch - as slow as the kernels it
 // replaced). With two groups a workgroup takes 8 token positions of BOTH modalities (wave 2p: x row, 2p+1: y row of
 // position 8b+p), so the mix needs only LDS.
+// A (fp32, tot4 float4) -> bf16 in LDS by the 1024 threads of a workgroup, four loads in flight per thread (one load per
+// iteration of a runtime-trip loop is one dependent L2 round trip each: 6 of them at C = 3072, R = 4)
+__device__ __forceinline__ void stage_lora_a(const float* __restrict__ A, bf16_t* Al, int tot4) {
+  for (int base = threadIdx.x; base < tot4; base += 4096) {
+    float4 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + 1024 * u;
+      t[u] = *reinterpret_cast<const float4*>(A + 4 * (int64_t)(i < tot4 ? i : base));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + 1024 * u;
+      if (i < tot4) {
+        u32x2_t wv;
+        wv.x = pack_bf16x2(t[u].x, t[u].y);
+        wv.y = pack_bf16x2(t[u].z, t[u].w);
+        *reinterpret_cast<u32x2_t*>(Al + 4 * (int64_t)i) = wv;
+      }
+    }
+  }
+}
+
 template <typename TIn, int R, bool MIX, int NVL>
 __global__ __launch_bounds__(1024) void ln_fwd_lora_kernel(const TIn* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, bf16_t* __restrict__ y, int64_t ldy,
@@ -129,13 +152,7 @@ __global__ __launch_bounds__(1024) void ln_fwd_lora_kernel(const TIn* __restrict
   }
   {   // stage A (fp32 -> bf16) while the row loads are in flight
     const int tot4 = n_groups * R * nv;
-    for (int i = threadIdx.x; i < tot4; i += 1024) {
-      const float4 t = *reinterpret_cast<const float4*>(A + 4 * (int64_t)i);
-      u32x2_t wv;
-      wv.x = pack_bf16x2(t.x, t.y);
-      wv.y = pack_bf16x2(t.z, t.w);
-      *reinterpret_cast<u32x2_t*>(Al + 4 * (int64_t)i) = wv;
-    }
+    stage_lora_a(A, Al, tot4);
   }
   float p[R];
 #pragma unroll
@@ -221,91 +238,95 @@ __global__ __launch_bounds__(1024) void ln_fwd_lora_kernel(const TIn* __restrict
 template <int R, bool MIX>
 __global__ __launch_bounds__(1024) void lora_down_mix_kernel(const bf16_t* __restrict__ x, int64_t ldx, int64_t rows, int C, const float* __restrict__ A,
                                                              int64_t half, int n_groups, float* __restrict__ a_out, const float* __restrict__ wx,
-                                                             const float* __restrict__ wy, float* __restrict__ U) {
+                                                             const float* __restrict__ wy, float* __restrict__ U, int64_t nblk) {
   extern __shared__ __align__(16) unsigned char ln_lds[];
   bf16_t* Al = reinterpret_cast<bf16_t*>(ln_lds);                                 // [G][R][C] bf16
   float* al = reinterpret_cast<float*>(ln_lds + (size_t)n_groups * R * C * 2);    // [8][2][R]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int g = 0;
-  int64_t row;
-  bool valid;
-  if (n_groups == 2) {
-    g = w & 1;
-    const int64_t t = 8 * (int64_t)blockIdx.x + (w >> 1);
-    valid = t < half;
-    row = g * half + t;
-  } else {
-    row = (int64_t)blockIdx.x * 16 + w;
-    valid = row < rows;
-  }
+  const int g = n_groups == 2 ? (w & 1) : 0;
   const int n8 = C >> 3;                       // 16-byte chunks per row
   constexpr int NCH = 8;                       // up to 8 chunks per lane: C <= 4096
-  u32x4_t v[NCH];
-  if (valid) {
-    const bf16_t* xr = x + row * ldx;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c8 = lane + 64 * i;
-      if (c8 < n8) v[i] = *reinterpret_cast<const u32x4_t*>(xr + 8 * c8);
+  // Persistent: a workgroup stages A once (it is n_groups*R*C floats - 98 KB at C = 3072 - and with one 16-row block per
+  // workgroup every block paid that read and its barrier) and then walks 16-row blocks blockIdx.x, + gridDim.x, ...
+  auto locate = [&](int64_t blk, int64_t* row) -> bool {
+    if (n_groups == 2) {
+      const int64_t t = 8 * blk + (w >> 1);
+      *row = g * half + t;
+      return blk < nblk && t < half;
     }
-  }
+    *row = blk * 16 + w;
+    return blk < nblk && *row < rows;
+  };
+  auto request = [&](bool ok, int64_t row, u32x4_t (&v)[NCH]) {
+    if (ok) {
+      const bf16_t* xr = x + row * ldx;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c8 = lane + 64 * i;
+        if (c8 < n8) v[i] = *reinterpret_cast<const u32x4_t*>(xr + 8 * c8);
+      }
+    }
+  };
+  u32x4_t v[NCH];
+  int64_t row;
+  bool valid = locate(blockIdx.x, &row);
+  request(valid, row, v);
   {
     const int tot4 = n_groups * R * (C >> 2);
-    for (int i = threadIdx.x; i < tot4; i += 1024) {
-      const float4 t = *reinterpret_cast<const float4*>(A + 4 * (int64_t)i);
-      u32x2_t wv;
-      wv.x = pack_bf16x2(t.x, t.y);
-      wv.y = pack_bf16x2(t.z, t.w);
-      *reinterpret_cast<u32x2_t*>(Al + 4 * (int64_t)i) = wv;
-    }
+    stage_lora_a(A, Al, tot4);
   }
   __syncthreads();
-  float p[R];
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    float p[R];
 #pragma unroll
-  for (int j = 0; j < R; ++j) p[j] = 0.f;
-  if (valid) {
-    const bf16_t* Ag = Al + (size_t)g * R * C;
+    for (int j = 0; j < R; ++j) p[j] = 0.f;
+    if (valid) {
+      const bf16_t* Ag = Al + (size_t)g * R * C;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c8 = lane + 64 * i;
-      if (c8 < n8) {
-        const float o[8] = {bf16_lo(v[i].x), bf16_hi(v[i].x), bf16_lo(v[i].y), bf16_hi(v[i].y), bf16_lo(v[i].z), bf16_hi(v[i].z), bf16_lo(v[i].w), bf16_hi(v[i].w)};
+      for (int i = 0; i < NCH; ++i) {
+        const int c8 = lane + 64 * i;
+        if (c8 < n8) {
+          const float o[8] = {bf16_lo(v[i].x), bf16_hi(v[i].x), bf16_lo(v[i].y), bf16_hi(v[i].y), bf16_lo(v[i].z), bf16_hi(v[i].z), bf16_lo(v[i].w), bf16_hi(v[i].w)};
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-          const u32x4_t av = *reinterpret_cast<const u32x4_t*>(Ag + (size_t)j * C + 8 * c8);
-          p[j] = fmaf(o[0], bf16_lo(av.x), fmaf(o[1], bf16_hi(av.x), fmaf(o[2], bf16_lo(av.y), fmaf(o[3], bf16_hi(av.y),
-                 fmaf(o[4], bf16_lo(av.z), fmaf(o[5], bf16_hi(av.z), fmaf(o[6], bf16_lo(av.w), fmaf(o[7], bf16_hi(av.w), p[j]))))))));
+          for (int j = 0; j < R; ++j) {
+            const u32x4_t av = *reinterpret_cast<const u32x4_t*>(Ag + (size_t)j * C + 8 * c8);
+            p[j] = fmaf(o[0], bf16_lo(av.x), fmaf(o[1], bf16_hi(av.x), fmaf(o[2], bf16_lo(av.y), fmaf(o[3], bf16_hi(av.y),
+                   fmaf(o[4], bf16_lo(av.z), fmaf(o[5], bf16_hi(av.z), fmaf(o[6], bf16_lo(av.w), fmaf(o[7], bf16_hi(av.w), p[j]))))))));
+          }
         }
       }
     }
-  }
-  int jb = 0, off = 32;
+    int jb = 0, off = 32;
 #pragma unroll
-  for (int n = R; n > 1; n >>= 1, off >>= 1) {
-    const bool up = (lane & off) != 0;
+    for (int n = R; n > 1; n >>= 1, off >>= 1) {
+      const bool up = (lane & off) != 0;
 #pragma unroll
-    for (int i = 0; i < n / 2; ++i) {
-      const float send = up ? p[i] : p[i + n / 2];
-      const float recv = __shfl_xor(send, off, 64);
-      p[i] = (up ? p[i + n / 2] : p[i]) + recv;
+      for (int i = 0; i < n / 2; ++i) {
+        const float send = up ? p[i] : p[i + n / 2];
+        const float recv = __shfl_xor(send, off, 64);
+        p[i] = (up ? p[i + n / 2] : p[i]) + recv;
+      }
+      jb += up ? n / 2 : 0;
     }
-    jb += up ? n / 2 : 0;
-  }
-  for (; off > 0; off >>= 1) p[0] += __shfl_xor(p[0], off, 64);
-  const bool writer = (lane & (64 / R - 1)) == 0;
-  if (valid && writer) a_out[row * R + jb] = p[0];
-  if (MIX) {
-    if (writer) al[((w >> 1) * 2 + g) * R + jb] = p[0];
-    __syncthreads();
-    if (valid && lane < 2 * R) {
-      const float fx = wx[0], fy = wy[0];
-      const int jj = lane < R ? lane : lane - R;
-      const float ax = al[((w >> 1) * 2 + 0) * R + jj], ay = al[((w >> 1) * 2 + 1) * R + jj];
-      float u;
-      if (g == 0) u = lane < R ? fx * ax : (1.f - fx) * ay;
-      else u = lane < R ? (1.f - fy) * ax : fy * ay;
-      U[row * 2 * R + lane] = u;
+    for (; off > 0; off >>= 1) p[0] += __shfl_xor(p[0], off, 64);
+    const bool writer = (lane & (64 / R - 1)) == 0;
+    if (valid && writer) a_out[row * R + jb] = p[0];
+    if (MIX) {
+      if (writer) al[((w >> 1) * 2 + g) * R + jb] = p[0];
+      __syncthreads();
+      if (valid && lane < 2 * R) {
+        const float fx = wx[0], fy = wy[0];
+        const int jj = lane < R ? lane : lane - R;
+        const float ax = al[((w >> 1) * 2 + 0) * R + jj], ay = al[((w >> 1) * 2 + 1) * R + jj];
+        float u;
+        if (g == 0) u = lane < R ? fx * ax : (1.f - fx) * ay;
+        else u = lane < R ? (1.f - fy) * ax : fy * ay;
+        U[row * 2 * R + lane] = u;
+      }
+      __syncthreads();                       // `al` is rewritten by the next block
     }
+    valid = locate(blk + gridDim.x, &row);     // (a second register set for a prefetch spills at 16 waves per workgroup: 128 VGPRs)
+    request(valid, row, v);
   }
 }
 
@@ -476,8 +497,8 @@ extern "C" int mfnet_lora_down_mix(const void* x, int64_t ldx, int64_t rows, int
   const int64_t half = rows / 2;
   const int64_t nblk = n_groups == 2 ? ceil_div64(half, 8) : ceil_div64(rows, 16);
   MF_CHECK_ARG(nblk < (1ll << 31), "lora_down_mix: too many rows");
-  dim3 grid((unsigned)nblk), block(1024);
-#define LDM(RR, MX) hipLaunchKernelGGL((lora_down_mix_kernel<RR, MX>), grid, block, lds, stream, (const bf16_t*)x, ldx, rows, (int)C, A, half, n_groups, a_out, wx, wy, U)
+  dim3 grid((unsigned)(nblk < 256 ? nblk : 256)), block(1024);      // persistent: one 16-wave workgroup per CU walks the blocks
+#define LDM(RR, MX) hipLaunchKernelGGL((lora_down_mix_kernel<RR, MX>), grid, block, lds, stream, (const bf16_t*)x, ldx, rows, (int)C, A, half, n_groups, a_out, wx, wy, U, nblk)
   if (R == 8 && U) LDM(8, true);
   else if (R == 8) LDM(8, false);
   else if (U) LDM(4, true);
