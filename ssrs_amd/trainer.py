@@ -30,7 +30,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import ops
-from .bank import ParamBank
+from .bank import ParamBank, weights_changed
 
 _ALIGN = 64          # elements: every tensor starts on a 256-byte boundary inside the flat buffers
 
@@ -181,6 +181,7 @@ class TrainEngine:
             return
         root = dist.get_global_rank(self.pg, src) if self.pg is not None else src
         dist.broadcast(self.flat_p, src=root, group=self.pg)
+        weights_changed()
         for b in self.model.buffers():
             if b.numel():
                 dist.broadcast(b, src=root, group=self.pg)
@@ -227,6 +228,7 @@ class TrainEngine:
     def optimizer_step(self):
         self._finish_exchange()
         ops.sgd_flat(self.flat_p, self.flat_g, self.flat_m, self.lr, self.momentum, self.weight_decay, 1.0 / self.world)
+        weights_changed()                 # the kernel rewrites the parameters without touching their version counters
 
     def step(self, rgb: torch.Tensor, dsm: torch.Tensor, target: torch.Tensor):
         """zero_grad -> forward -> CE -> backward (-> all-reduce) -> SGD. Returns the device tensor

@@ -436,3 +436,47 @@ def test_vitb_train_step_vs_reference():
     assert 0.7 < np.quantile(ratios, .05) and np.quantile(ratios, .95) < 1.4, ratios
     assert perr < 4e-3 and pnorm < 1e-3, (perr, pnorm)                                         # measured 1.8e-3 / 2.4e-4
     assert max(berr.values()) < 2e-2, berr                                                     # measured 8e-3
+
+
+def test_inference_operand_cache_never_serves_stale_weights():
+    """Under no_grad the operands derived from trainable weights (bf16 GEMM images, stacked LoRA factors, ...) are kept between
+    forwards (bank.derived). They must follow every way the weights can change: an in-place torch op, load_state_dict, and the
+    engine's SGD kernel, which rewrites the flat parameter buffer without touching version counters."""
+    from ssrs_amd import bank
+    from ssrs_amd.trainer import TrainEngine
+    m = _tiny_model("sam_lora")
+    m.load_state_dict(detfill.fill_state_dict(m.state_dict(), "cache/"))
+    m = m.cuda().eval()
+    rgb, dsm, tgt = [t.cuda() for t in detfill.tiles("cache", 2, 256, 6)]
+
+    def fresh():
+        bank._EVAL_CACHE.clear()
+        with torch.no_grad():
+            return m(rgb, dsm).clone()
+
+    def cached():
+        with torch.no_grad():
+            return m(rgb, dsm).clone()
+
+    a = fresh()
+    n_entries = len(bank._EVAL_CACHE)
+    assert n_entries > 20
+    assert torch.equal(cached(), a) and len(bank._EVAL_CACHE) == n_entries          # served from the cache, same bits
+    w = m.decoder.segmentation_head[2][0].weight
+    with torch.no_grad():
+        w.mul_(1.5)                                                                     # in-place torch op
+    b = cached()
+    assert not torch.equal(b, a) and torch.equal(b, fresh())
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["decoder.segmentation_head.2.0.weight"] = sd["decoder.segmentation_head.2.0.weight"] / 1.5
+    m.load_state_dict(sd)                                                              # load_state_dict
+    c = cached()
+    assert torch.allclose(c, a, rtol=1e-2, atol=1e-2) and torch.equal(c, fresh())
+    eng = TrainEngine(m.train(), lr=0.05, momentum=0.9, weight_decay=5e-4, class_weight=torch.ones(6, device="cuda"))
+    m.eval()
+    d0 = cached()
+    m.train()
+    eng.step(rgb, dsm, tgt)                                                            # SGD kernel on the flat buffer
+    m.eval()
+    d1 = cached()
+    assert not torch.equal(d1, d0) and torch.equal(d1, fresh())
