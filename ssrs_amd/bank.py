@@ -77,29 +77,28 @@ def derived(key, shape, dtype, fill: Callable[[torch.Tensor], List[Pair]], devic
         hit = bank.entries.get(key)
         if hit is not None:
             return hit[0]
-    elif not torch.is_grad_enabled():
-        # Inference (no_grad, no engine): the operand is kept and re-used while its sources are unchanged - their version
-        # counters (bumped by every in-place torch op, load_state_dict included) and WEIGHTS_EPOCH (bumped by whoever rewrites
-        # parameters behind torch's back: TrainEngine's SGD kernel, its broadcast) are compared on every call. A sliding-window
-        # forward re-derived ~240 operands per batch before (15 % of its kernel time in gather / fill launches).
-        hit = _EVAL_CACHE.get(key)
+    elif EvalBank.active is not None and not torch.is_grad_enabled():
+        # Inference inside a predictor's EvalBank: the operand is kept and re-used while its sources are unchanged - their
+        # version counters (bumped by every in-place torch op, load_state_dict included) and WEIGHTS_EPOCH (bumped by whoever
+        # rewrites parameters behind torch's back: TrainEngine's SGD kernel, its broadcast, a training-mode BatchNorm) are
+        # compared on every call. A sliding-window forward re-derived ~240 operands per batch before (15 % of its kernel time
+        # in gather / fill launches). Keys carry data_ptr()s, so the store belongs to ONE predictor, whose forward keeps its
+        # model alive (a process-wide store could hand a freed model's operand to a new model at the same address). Under
+        # graph capture a stored operand is used as it is (GraphedForward validates the store before every replay and
+        # refreshes changed operands in place); a key first seen under capture is built inside the graph and not stored.
+        eb = EvalBank.active
+        capturing = torch.cuda.is_current_stream_capturing()
+        hit = eb.entries.get(key)
         if hit is not None and tuple(hit[0].shape) == tuple(shape) and hit[0].dtype == dtype:
-            t = hit[0]
+            if not capturing:
+                eb.check(key, hit)
+            return hit[0]
+        if not capturing:
+            t = torch.zeros(shape, dtype=dtype, device=device)
             pairs = fill(t)
-            sig = _signature(pairs)
-            if sig == hit[1]:
-                return t
-            t.zero_()
             ops.gather(pairs)
-            _EVAL_CACHE[key] = (t, sig)
+            eb.entries[key] = [t, pairs, _signature(pairs)]
             return t
-        t = torch.zeros(shape, dtype=dtype, device=device)
-        pairs = fill(t)
-        ops.gather(pairs)
-        if len(_EVAL_CACHE) >= 8192:          # keys carry data_ptr()s: entries of freed models would pile up
-            _EVAL_CACHE.clear()
-        _EVAL_CACHE[key] = (t, _signature(pairs))
-        return t
     t = torch.zeros(shape, dtype=dtype, device=device)
     with torch.no_grad():
         pairs = fill(t)
@@ -109,8 +108,40 @@ def derived(key, shape, dtype, fill: Callable[[torch.Tensor], List[Pair]], devic
     return t
 
 
-_EVAL_CACHE = {}
-WEIGHTS_EPOCH = [0]
+WEIGHTS_EPOCH = ops.WEIGHTS_EPOCH          # one counter for every cache of weight-derived tensors (ops.bn_forward's included)
+
+
+class EvalBank:
+    """Store of weight-derived operands for inference: a predictor owns one and runs its forwards inside it."""
+    active: Optional["EvalBank"] = None
+
+    def __init__(self):
+        self.entries, self.bn = {}, {}
+
+    def __enter__(self):
+        self._prev = (EvalBank.active, ops._BN_EVAL)
+        EvalBank.active, ops._BN_EVAL = self, self.bn
+        return self
+
+    def __exit__(self, *exc):
+        EvalBank.active, ops._BN_EVAL = self._prev
+        return False
+
+    def check(self, key, ent):
+        """re-fill the operand in place if one of its sources changed since it was written"""
+        sig = _signature(ent[1])
+        if sig != ent[2]:
+            ent[0].zero_()
+            ops.gather(ent[1])
+            ent[2] = sig
+
+    def validate(self):
+        """every stored operand against its sources (before a graph replay that reads them): a few hundred integer
+        compares; changed ones are re-filled in place, so a captured forward sees the new values at the same addresses"""
+        for key, ent in self.entries.items():
+            self.check(key, ent)
+        for key, ent in self.bn.items():
+            ops.bn_eval_check(ent)
 
 
 def weights_changed():

@@ -26,6 +26,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
+from .bank import EvalBank
 
 
 # ---------------------------------------------------------------------------------------------- window grids (host)
@@ -205,6 +206,8 @@ class GraphedForward:
                 out = self.forward(srgb, sdsm)
             ent = self._graphs[key] = (g, srgb, sdsm, out)
         g, srgb, sdsm, out = ent
+        if EvalBank.active is not None:
+            EvalBank.active.validate()        # the graph reads the stored weight-derived operands: refreshed in place if stale
         srgb.copy_(rgb, non_blocking=True)
         sdsm.copy_(dsm, non_blocking=True)
         g.replay()
@@ -225,6 +228,7 @@ class SlidingWindowPredictor:
         if accumulate not in (torch.float32, torch.float64):
             raise ValueError("accumulate: torch.float32 or torch.float64")
         self.accumulate = accumulate
+        self._ebank = EvalBank()           # weight-derived operands kept between this predictor's forwards (bank.derived)
 
     @torch.no_grad()
     def predict(self, img: torch.Tensor, dsm: torch.Tensor, stride: int, return_scores: bool = False):
@@ -249,7 +253,8 @@ class SlidingWindowPredictor:
         for chunk in grouper(self.batch_size, mine):
             c4 = _coords4([(r, c, h, w) for r, c in chunk], H, W, h, w, img.device)
             rgb_t, dsm_t = ops.extract_tiles(img, d, c4, h, w)
-            logits = self.forward(rgb_t, dsm_t).float().contiguous()
+            with self._ebank:
+                logits = self.forward(rgb_t, dsm_t).float().contiguous()
             c2 = (c4[:, :2] - torch.tensor([me["lo"], 0], dtype=torch.int32, device=img.device)).contiguous()
             ops.tile_accumulate(band, logits, c2, atomic=True)              # pred[x:x+w, y:y+h] += out (evaluator.py:169-171)
         if world > 1 and rank < len(plan):
@@ -314,6 +319,7 @@ class RasterInference:
         self.forward, self.window_size = (GraphedForward(forward) if graph else forward), tuple(window_size)
         self.overlap = int(self.window_size[0] * overlap_ratio)                 # inference.py:139-141
         self.batch_size, self.cls, self.threshold, self.group = batch_size, building_class, threshold, group
+        self._ebank = EvalBank()           # weight-derived operands kept between this predictor's forwards (bank.derived)
 
     @staticmethod
     def normalize_image(image: torch.Tensor, is_rgb: bool = True, nodata_value=None):
@@ -341,7 +347,8 @@ class RasterInference:
             c4 = _coords4([(y, x, ye - y, xe - x) for y, x, ye, xe in chunk], H, W, h, w, img.device)
             rgb_t, dem_t = ops.extract_tiles(img, demc, c4, h, w)
             ops.tile_minmax_norm(dem_t)
-            logits = self.forward(rgb_t, dem_t).float().contiguous()
+            with self._ebank:
+                logits = self.forward(rgb_t, dem_t).float().contiguous()
             prob, mask = ops.tile_prob_mask(logits, c4, self.cls, self.threshold, want_prob)
             mask_h = mask.cpu().numpy()
             prob_h = prob.cpu().numpy() if want_prob else None
@@ -368,7 +375,8 @@ class RasterInference:
             c4 = _coords4([(y, x, ye - y, xe - x) for y, x, ye, xe in chunk], H, W, h, w, img.device)
             rgb_t, dem_t = ops.extract_tiles(img, demc, c4, h, w)              # reflect-pads short tiles
             ops.tile_minmax_norm(dem_t)                                        # per-tile DSM min-max
-            logits = self.forward(rgb_t, dem_t).float().contiguous()
+            with self._ebank:
+                logits = self.forward(rgb_t, dem_t).float().contiguous()
             c4b = c4.clone()
             c4b[:, 0] -= me["lo"]
             ops.tile_prob_accumulate(band[0], band[1], logits, c4b.contiguous(), self.cls)

@@ -718,6 +718,21 @@ def coldot(a, b, G, P):
     return out
 
 
+WEIGHTS_EPOCH = [0]      # bumped (bank.weights_changed) by code that rewrites parameters / buffers without a torch in-place op
+_BN_EVAL = None          # the active bank.EvalBank's store of eval-mode BatchNorm mean / rstd (None: no store)
+
+
+def bn_eval_check(ent):
+    """stored eval statistics [st, sig, run_mean, run_var, eps] re-derived in place if the running statistics changed"""
+    st, sig, run_mean, run_var, eps = ent
+    cur = (WEIGHTS_EPOCH[0], run_mean._version, run_var._version)
+    if cur != sig:
+        C = run_mean.shape[0]
+        call("mfnet_bn_finalize", None, None, st[0].data_ptr(), st[1].data_ptr(), run_mean.data_ptr(), run_var.data_ptr(), None,
+             C, 1, eps, 0.1, 0, _stream(st))
+        ent[1] = cur
+
+
 def bn_forward(x, gamma, beta, run_mean, run_var, nbt, training, eps=1e-5, momentum=0.1, act=ACT_NONE, chan_scale=None,
                rows_per_image=0, out_dtype=torch.float32, out2_dtype=None):
     """BatchNorm2d on a channels-last [rows, C] map. -> (y, y2 | None, mean, rstd)."""
@@ -727,6 +742,8 @@ def bn_forward(x, gamma, beta, run_mean, run_var, nbt, training, eps=1e-5, momen
     st = torch.empty((2, C), dtype=torch.float32, device=x.device)
     y = torch.empty((rows, C), dtype=out_dtype, device=x.device)
     y2 = torch.empty((rows, C), dtype=out2_dtype, device=x.device) if out2_dtype is not None else None
+    if training and run_mean is not None:
+        WEIGHTS_EPOCH[0] += 1            # the kernels below rewrite the running statistics (no version bump)
     if training and C <= 1024:
         s, sq = colsum(x, 1, rows, want_sq=True)
         call("mfnet_bn_train_apply", x.data_ptr(), _dt(x), s.data_ptr(), sq.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), _p(run_mean),
@@ -738,8 +755,21 @@ def bn_forward(x, gamma, beta, run_mean, run_var, nbt, training, eps=1e-5, momen
         call("mfnet_bn_finalize", s.data_ptr(), sq.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), _p(run_mean), _p(run_var),
              _p(nbt), C, rows, float(eps), float(momentum), 1, _stream(x))
     else:
-        call("mfnet_bn_finalize", None, None, st[0].data_ptr(), st[1].data_ptr(), run_mean.data_ptr(), run_var.data_ptr(), None,
-             C, rows, float(eps), float(momentum), 0, _stream(x))
+        # eval: mean / rstd follow from the running statistics alone - inside a predictor's EvalBank they are kept between calls
+        # (validated like bank.derived's operands: version counters + WEIGHTS_EPOCH), one launch less per BatchNorm and forward
+        key = (run_mean.data_ptr(), run_var.data_ptr(), float(eps), C)
+        store = _BN_EVAL if (_BN_EVAL is not None and not torch.is_grad_enabled()) else None
+        ent = store.get(key) if store is not None else None
+        capturing = torch.cuda.is_current_stream_capturing()
+        if ent is not None:
+            if not capturing:
+                bn_eval_check(ent)
+            st = ent[0]
+        else:
+            call("mfnet_bn_finalize", None, None, st[0].data_ptr(), st[1].data_ptr(), run_mean.data_ptr(), run_var.data_ptr(), None,
+                 C, rows, float(eps), float(momentum), 0, _stream(x))
+            if store is not None and not capturing:
+                store[key] = [st, (WEIGHTS_EPOCH[0], run_mean._version, run_var._version), run_mean, run_var, float(eps)]
     call("mfnet_bn_apply", x.data_ptr(), _dt(x), st[0].data_ptr(), st[1].data_ptr(), gamma.data_ptr(), beta.data_ptr(), act,
          _p(chan_scale), rows_per_image, y.data_ptr(), _dt(y), _p(y2), _dt(y2) if y2 is not None else 0, rows, C, _stream(x))
     return y, y2, st[0], st[1]

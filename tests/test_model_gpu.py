@@ -439,8 +439,8 @@ def test_vitb_train_step_vs_reference():
 
 
 def test_inference_operand_cache_never_serves_stale_weights():
-    """Under no_grad the operands derived from trainable weights (bf16 GEMM images, stacked LoRA factors, ...) are kept between
-    forwards (bank.derived). They must follow every way the weights can change: an in-place torch op, load_state_dict, and the
+    """Inside a predictor's EvalBank the operands derived from trainable weights (bf16 GEMM images, stacked LoRA factors, ...)
+    are kept between forwards (bank.derived). They must follow every way the weights can change: an in-place torch op, load_state_dict, and the
     engine's SGD kernel, which rewrites the flat parameter buffer without touching version counters."""
     from ssrs_amd import bank
     from ssrs_amd.trainer import TrainEngine
@@ -449,19 +449,22 @@ def test_inference_operand_cache_never_serves_stale_weights():
     m = m.cuda().eval()
     rgb, dsm, tgt = [t.cuda() for t in detfill.tiles("cache", 2, 256, 6)]
 
+    eb = bank.EvalBank()
+
     def fresh():
-        bank._EVAL_CACHE.clear()
         with torch.no_grad():
-            return m(rgb, dsm).clone()
+            return m(rgb, dsm).clone()             # no EvalBank: every operand is derived anew
 
     def cached():
-        with torch.no_grad():
+        with torch.no_grad(), eb:
             return m(rgb, dsm).clone()
 
     a = fresh()
-    n_entries = len(bank._EVAL_CACHE)
-    assert n_entries > 20
-    assert torch.equal(cached(), a) and len(bank._EVAL_CACHE) == n_entries          # served from the cache, same bits
+    assert torch.equal(cached(), a)
+    n_entries = len(eb.entries)
+    assert n_entries > 20 and len(eb.bn) > 5
+    assert torch.equal(cached(), a) and len(eb.entries) == n_entries                # served from the store, same bits
+    assert bank.EvalBank.active is None
     w = m.decoder.segmentation_head[2][0].weight
     with torch.no_grad():
         w.mul_(1.5)                                                                     # in-place torch op
@@ -472,6 +475,24 @@ def test_inference_operand_cache_never_serves_stale_weights():
     m.load_state_dict(sd)                                                              # load_state_dict
     c = cached()
     assert torch.allclose(c, a, rtol=1e-2, atol=1e-2) and torch.equal(c, fresh())
+    # a forward replayed from a HIP graph reads the stored operands: they are refreshed in place before the replay
+    from ssrs_amd.inference import GraphedForward
+    gf = GraphedForward(lambda x, y: m(x, y))
+    for _ in range(3):                             # eager warm-up, capture, replay
+        with eb:
+            g = gf(rgb, dsm).clone()
+        assert torch.equal(g, c)
+    with torch.no_grad():
+        w.mul_(0.5)
+    with eb:
+        g = gf(rgb, dsm).clone()
+    assert not torch.equal(g, c) and torch.equal(g, fresh())
+    w.data.mul_(2.0)                               # behind torch's back (no version bump): the writer announces it
+    bank.weights_changed()
+    with eb:
+        g2 = gf(rgb, dsm).clone()
+    assert not torch.equal(g2, g) and torch.equal(g2, fresh())
+    # (an engine adopts the parameters into its flat buffer - new addresses: graphs captured before that are void)
     eng = TrainEngine(m.train(), lr=0.05, momentum=0.9, weight_decay=5e-4, class_weight=torch.ones(6, device="cuda"))
     m.eval()
     d0 = cached()
@@ -480,3 +501,25 @@ def test_inference_operand_cache_never_serves_stale_weights():
     m.eval()
     d1 = cached()
     assert not torch.equal(d1, d0) and torch.equal(d1, fresh())
+
+
+def test_eval_batchnorm_statistics_follow_a_training_forward():
+    """the cached eval mean / rstd of a BatchNorm (ops.bn_forward under no_grad) must follow the running statistics that a
+    training-mode forward rewrites in a kernel (no torch version bump)"""
+    m = _tiny_model("sam_lora")
+    m.load_state_dict(detfill.fill_state_dict(m.state_dict(), "bncache/"))
+    m = m.cuda().eval()
+    rgb, dsm, _ = [t.cuda() for t in detfill.tiles("bncache", 2, 256, 6)]
+    from ssrs_amd import bank
+    eb = bank.EvalBank()
+    with torch.no_grad(), eb:
+        a = m(rgb, dsm).clone()
+        assert torch.equal(m(rgb, dsm), a) and len(eb.bn) > 5
+    m.train()
+    m(rgb, dsm)                                   # updates every BatchNorm's running statistics
+    m.eval()
+    with torch.no_grad():
+        with eb:
+            b = m(rgb, dsm).clone()
+        c = m(rgb, dsm).clone()                   # no store
+    assert not torch.equal(b, a) and torch.equal(b, c)
