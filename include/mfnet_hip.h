@@ -12,8 +12,8 @@
  *     (thread-local). Nothing throws across the boundary.
  *   - all work is enqueued on `stream`; no entry point synchronises, allocates or frees device
  *     memory, or keeps device state. Caller owns every buffer. Two documented exceptions, both thread-safe: the
- *     attention entry points raise their kernels' dynamic-LDS limit once per device (a per-device "done" flag is all
- *     that is kept), and mfnet_colsum_static owns a scratch array (see there). The library reads no environment variable.
+ *     attention entry points and mfnet_lora_down_mix (LDS images above 64 KB) raise their kernels' dynamic-LDS limit once
+ *     per device (a per-device "done" flag is all that is kept), and mfnet_colsum_static owns a scratch array (see there). The library reads no environment variable.
  *   - "bf16" buffers hold raw bfloat16 bits; matrices are row-major; *_dtype is MFNET_F32 / MFNET_BF16.
  *   - shapes that would make a kernel read or write out of bounds are rejected with MFNET_ERR_ARG
  *     before anything is launched.

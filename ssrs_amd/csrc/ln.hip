@@ -6,6 +6,7 @@
 // LayerNorm2d on NCHW (medsam/models/common/layer_norm.py:12-17) and Norm2d
 // (unetformer_mmsam.py:14-22) - all the same op once tokens are channels-last.
 #include "common.h"
+#include <mutex>
 
 #define LN_MAXV 8   // float4 chunks per lane -> C <= 64*4*8 = 2048
 
@@ -492,7 +493,25 @@ extern "C" int mfnet_lora_down_mix(const void* x, int64_t ldx, int64_t rows, int
                "lora_down_mix: one group, or two contiguous groups [2][R][C] of rows/2 rows each");
   MF_CHECK_ARG(!U || (wx && wy && n_groups == 2), "lora_down_mix: the cross-modal mix needs wx, wy and two groups");
   const size_t lds = (size_t)n_groups * R * C * 2 + 8 * 2 * R * sizeof(float);
-  MF_CHECK_ARG(lds <= 64 * 1024, "lora_down_mix: G*R*C = %lld does not fit the 64 KB LDS image", (long long)n_groups * R * C);
+  MF_CHECK_ARG(lds <= 96 * 1024, "lora_down_mix: G*R*C = %lld does not fit the 96 KB LDS image", (long long)n_groups * R * C);
+  if (lds > 64 * 1024) {
+    // more than 64 KB of dynamic LDS needs the attribute once per device (C = 4096 with two groups of rank 4: ViT-L's lin2); the
+    // per-device flag is the only state kept (guarded: entry points may be called from any thread)
+    static std::mutex mu;
+    static bool done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { mfnet_set_error("lora_down_mix: hipGetDevice failed"); return MFNET_ERR_HIP; }
+    std::lock_guard<std::mutex> lk(mu);
+    if (!done[dev]) {
+      const void* fns[4] = {(const void*)lora_down_mix_kernel<8, true>, (const void*)lora_down_mix_kernel<8, false>,
+                            (const void*)lora_down_mix_kernel<4, true>, (const void*)lora_down_mix_kernel<4, false>};
+      for (int i = 0; i < 4; ++i) {
+        hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) { mfnet_set_error("lora_down_mix: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MFNET_ERR_HIP; }
+      }
+      done[dev] = true;
+    }
+  }
   if (rows == 0) return MFNET_OK;
   const int64_t half = rows / 2;
   const int64_t nblk = n_groups == 2 ? ceil_div64(half, 8) : ceil_div64(rows, 16);

@@ -221,7 +221,7 @@ def _mix_linear_fwd(x_bf, lin, half, act, residual, aU=None):
     K = x_bf.shape[-1]
     if aU is not None:
         a, U = aU
-    elif r in (4, 8) and half % 2 == 0 and K % 8 == 0 and K <= 4096 and _ln_lora_fits(r, K) and x_bf.shape[0] == 2 * half:
+    elif r in (4, 8) and half % 2 == 0 and K % 8 == 0 and K <= 4096 and 2 * r * K * 2 + 512 <= 96 * 1024 and x_bf.shape[0] == 2 * half:
         a, U = ops.lora_down_mix(x_bf, _stack2("A", lin.lora_Ax, lin.lora_Ay), lin.lora_wx.detach(), lin.lora_wy.detach())
     else:
         a = _down(x_bf, lin.lora_Ax, lin.lora_Ay, half)

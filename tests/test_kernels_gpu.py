@@ -84,7 +84,8 @@ def test_layernorm_fwd_with_lora_down_projection(ops, rows, C, R, mix):
     assert rel_err(a1, yd @ Ab[0].t()) < 1e-5
 
 
-@pytest.mark.parametrize("rows,C,R,mix", [(8192, 3072, 4, True), (512, 768, 8, False), (36, 128, 4, True), (64, 1024, 8, False)])
+@pytest.mark.parametrize("rows,C,R,mix", [(8192, 3072, 4, True), (512, 768, 8, False), (36, 128, 4, True), (64, 1024, 8, False),
+                                          (8192, 4096, 4, True), (1040, 4096, 4, False)])        # C = 4096: the 64-96 KB LDS image (ViT-L lin2)
 def test_lora_down_projection_and_mix_in_one_launch(ops, rows, C, R, mix):
     x = rnd(rows, C, seed=1).to(torch.bfloat16)
     A = 0.05 * rnd(2, R, C, seed=4)
