@@ -718,6 +718,25 @@ def coldot(a, b, G, P):
     return out
 
 
+# Synchronised BatchNorm (strict 1-vs-N equivalence of data-parallel training; torch.nn.SyncBatchNorm's arithmetic):
+# None = per-replica statistics. TrainEngine(sync_bn=True) sets it to (process_group,) - then the training-mode column sums
+# (sum x, sum x^2, rows) and the backward sums (sum dy, sum dy*xhat, rows) are all-reduced over the group before they are used.
+# The collectives sit between kernels of the step, so this mode runs eagerly (no HIP-graph replay).
+SYNC_BN = None
+
+
+def _sync_sums(parts, rows):
+    """all-reduce [parts..., rows] over the SyncBN group -> (summed parts, total rows)"""
+    import torch.distributed as dist
+    flat = torch.cat([p.reshape(-1) for p in parts] + [torch.tensor([float(rows)], dtype=torch.float32, device=parts[0].device)])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=SYNC_BN[0])
+    out, o = [], 0
+    for p in parts:
+        out.append(flat[o:o + p.numel()].view(p.shape))
+        o += p.numel()
+    return out, int(round(flat[-1].item()))
+
+
 WEIGHTS_EPOCH = [0]      # bumped (bank.weights_changed) by code that rewrites parameters / buffers without a torch in-place op
 _BN_EVAL = None          # the active bank.EvalBank's store of eval-mode BatchNorm mean / rstd (None: no store)
 
@@ -744,13 +763,21 @@ def bn_forward(x, gamma, beta, run_mean, run_var, nbt, training, eps=1e-5, momen
     y2 = torch.empty((rows, C), dtype=out2_dtype, device=x.device) if out2_dtype is not None else None
     if training and run_mean is not None:
         WEIGHTS_EPOCH[0] += 1            # the kernels below rewrite the running statistics (no version bump)
-    if training and C <= 1024:
+    n_stat = rows
+    if training and SYNC_BN is not None:
+        s, sq = colsum(x, 1, rows, want_sq=True)
+        (s, sq), n_stat = _sync_sums([s, sq], rows)
+        call("mfnet_bn_finalize", s.data_ptr(), sq.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), _p(run_mean), _p(run_var),
+             _p(nbt), C, n_stat, float(eps), float(momentum), 1, _stream(x))
+    elif training and C <= 1024:
         s, sq = colsum(x, 1, rows, want_sq=True)
         call("mfnet_bn_train_apply", x.data_ptr(), _dt(x), s.data_ptr(), sq.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), _p(run_mean),
              _p(run_var), _p(nbt), float(eps), float(momentum), gamma.data_ptr(), beta.data_ptr(), act, _p(chan_scale), rows_per_image,
              y.data_ptr(), _dt(y), _p(y2), _dt(y2) if y2 is not None else 0, rows, C, _stream(x))
         return y, y2, st[0], st[1]
-    if training:
+    if training and SYNC_BN is not None:
+        pass
+    elif training:
         s, sq = colsum(x, 1, rows, want_sq=True)
         call("mfnet_bn_finalize", s.data_ptr(), sq.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), _p(run_mean), _p(run_var),
              _p(nbt), C, rows, float(eps), float(momentum), 1, _stream(x))
@@ -786,8 +813,14 @@ def bn_backward(dy, x, mean, rstd, gamma, beta, training, act=ACT_NONE, chan_sca
          beta.data_ptr(), act, _p(chan_scale), rows_per_image, sums[0].data_ptr(), sums[1].data_ptr(), rows, C,
          ws.data_ptr(), tk.data_ptr(), _stream(x))
     dx = torch.empty((rows, C), dtype=dx_dtype, device=x.device)
+    use = sums
+    if training and SYNC_BN is not None:
+        # dx takes the group-wide means of dy and dy*xhat (the kernel divides by its own row count: pre-scale by rows / total);
+        # dgamma / dbeta stay this rank's sums - the gradient exchange adds the ranks
+        (g,), n_tot = _sync_sums([sums.clone()], rows)
+        use = g * (float(rows) / float(n_tot))
     call("mfnet_bn_bwd_apply", dy.data_ptr(), _dt(dy), x.data_ptr(), _dt(x), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
-         beta.data_ptr(), act, _p(chan_scale), rows_per_image, sums[0].data_ptr(), sums[1].data_ptr(), 1 if training else 0,
+         beta.data_ptr(), act, _p(chan_scale), rows_per_image, use[0].data_ptr(), use[1].data_ptr(), 1 if training else 0,
          dx.data_ptr(), _dt(dx), rows, C, _stream(x))
     return dx, sums[1], sums[0]
 

@@ -85,7 +85,7 @@ class TrainEngine:
     def __init__(self, model: nn.Module, lr: float = 0.01, momentum: float = 0.9, weight_decay: float = 5e-4,
                  milestones: Sequence[int] = (25, 35, 45), gamma: float = 0.1, class_weight: Optional[torch.Tensor] = None,
                  ignore_index: int = -100, process_group=None, overlap: bool = True, use_graph: bool = False,
-                 exchange_when_alone: bool = False):
+                 exchange_when_alone: bool = False, sync_bn: bool = False):
         self.model = model
         self.exchange_when_alone = bool(exchange_when_alone)      # world 1 still calls the collective (rehearsals)
         self.base_lr, self.momentum, self.weight_decay = float(lr), float(momentum), float(weight_decay)
@@ -99,6 +99,11 @@ class TrainEngine:
         # and replayed (the step is ~2300 kernel launches: eager host enqueue time is 23 ms of a 29 ms step).
         # The gradient exchange and the SGD kernel (whose lr changes with the schedule) stay outside the graph.
         self.use_graph = bool(use_graph)
+        # sync_bn: BatchNorm batch statistics over the whole data-parallel group (the strict 1-vs-N mode; default is
+        # per-replica statistics like DDP). Its collectives sit between kernels of the step, so the step is enqueued eagerly.
+        self.sync_bn = bool(sync_bn) and self.world > 1
+        if self.sync_bn and self.use_graph:
+            raise ValueError("sync_bn exchanges statistics inside the step: use_graph=False")
         self.overlap = overlap and not self.use_graph        # autograd hooks do not run when a graph is replayed
         self._graphs = {}
         self._eager_warmup = 2
@@ -217,12 +222,16 @@ class TrainEngine:
 
     def forward_backward(self, rgb, dsm, target, want_pred=False):
         """-> (acc [4] device tensor: sum w*nll, sum w, #correct, #valid ; pred uint8 | None)."""
-        with self.bank, self.arena:   # bank: refreshes every operand derived from trainable weights, then serves them
-            out = self.model(rgb, dsm, mode="Train")
-            out = out.contiguous()
-            acc, pred = ops.ce_loss_fwd(out, target, self.class_weight, self.ignore_index, want_pred=want_pred)
-            d = ops.ce_loss_bwd(out, target, acc, self.class_weight, self.ignore_index, 1.0)
-            out.backward(d)
+        ops.SYNC_BN = (self.pg,) if self.sync_bn else None
+        try:
+            with self.bank, self.arena:   # bank: refreshes every operand derived from trainable weights, then serves them
+                out = self.model(rgb, dsm, mode="Train")
+                out = out.contiguous()
+                acc, pred = ops.ce_loss_fwd(out, target, self.class_weight, self.ignore_index, want_pred=want_pred)
+                d = ops.ce_loss_bwd(out, target, acc, self.class_weight, self.ignore_index, 1.0)
+                out.backward(d)
+        finally:
+            ops.SYNC_BN = None
         return acc, pred
 
     def optimizer_step(self):

@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _tiny():
+def _tiny(train=False):
     import argparse
     import warnings
     from ssrs_amd import detfill
@@ -20,9 +20,9 @@ def _tiny():
     args = argparse.Namespace(mod="sam_lora", mid_dim=None, image_size=1024, multimask_output=1)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        m = UNetFormer(num_classes=6, encoder="vit_tiny_test", args=args)
+        m = UNetFormer(num_classes=6, encoder="vit_tiny_test", args=args, dropout=0.0 if train else 0.1)
     m.load_state_dict(detfill.fill_state_dict(m.state_dict(), "dp/"))
-    return m.cuda().eval()
+    return m.cuda().train() if train else m.cuda().eval()
 
 
 def _stage_collectives():
@@ -101,4 +101,73 @@ def test_two_rank_gradients_equal_single_process_gradients():
     for rank, worst, err in res:
         assert err is None, err
         assert worst < 1e-5, (rank, worst)              # measured 2e-7 .. 3e-7
+    assert all(p.exitcode == 0 for p in procs)
+
+
+def _bn_buffers(m):
+    return torch.cat([b.detach().float().reshape(-1) for n, b in m.named_buffers() if n.endswith(("running_mean", "running_var"))])
+
+
+def _worker_sync_bn(rank, world, port, q):
+    """BatchNorm in TRAINING mode: with sync_bn the two ranks' one-tile batches must behave like the single-process two-tile
+    batch (torch.nn.SyncBatchNorm's contract; SURVEY 8(e) strict 1-vs-N mode) - loss, averaged gradients, running statistics.
+    Per-replica statistics (the default) are measured beside it: they must be far off, or the test proves nothing."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        _stage_collectives()
+        from ssrs_amd import detfill, ops
+        from ssrs_amd.trainer import TrainEngine, trainable_tensors
+        rgb, dsm, tgt = [t.cuda() for t in detfill.tiles("dpbn", 2, 256, 6)]
+        w = torch.ones(6, device="cuda")
+        ref_m = _tiny(train=True)
+        named, _ = trainable_tensors(ref_m)
+        out = ref_m(rgb, dsm, mode="Train").contiguous()
+        acc, _ = ops.ce_loss_fwd(out, tgt, w, -100)
+        out.backward(ops.ce_loss_bwd(out, tgt, acc, w, -100, 1.0))
+        ref = torch.cat([p.grad.reshape(-1) for _, p in named])
+        ref_loss = (acc[0] / acc[1]).item()
+        ref_buf = _bn_buffers(ref_m)
+        res = {}
+        for sync in (True, False):
+            m = _tiny(train=True)
+            eng = TrainEngine(m, lr=0.01, momentum=0.9, weight_decay=5e-4, class_weight=w, overlap=False, sync_bn=sync)
+            sl = slice(rank, rank + 1)
+            eng.zero_grad()
+            a, _ = eng.forward_backward(rgb[sl].contiguous(), dsm[sl].contiguous(), tgt[sl].contiguous())
+            eng._finish_exchange()
+            a = a.clone()
+            dist.all_reduce(a)
+            got = torch.cat([p.grad.reshape(-1) for p in eng.params]) / world
+            res[sync] = (((got - ref).norm() / ref.norm()).item(), abs((a[0] / a[1]).item() - ref_loss),
+                         ((_bn_buffers(m) - ref_buf).abs().max() / ref_buf.abs().max()).item())
+        q.put((rank, res, None))
+    except Exception as e:                                    # noqa: BLE001
+        import traceback
+        q.put((rank, None, traceback.format_exc()))
+        raise e
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_sync_bn_two_ranks_equal_single_process_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_sync_bn, args=(r, 2, 29641, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+    for rank, r, err in res:
+        assert err is None, err
+        print(f"rank {rank}: sync_bn grad L2 {r[True][0]:.2e} loss {r[True][1]:.2e} running stats {r[True][2]:.2e} | "
+              f"per-replica grad L2 {r[False][0]:.2e} loss {r[False][1]:.2e} running stats {r[False][2]:.2e}")
+        # bf16 roundings carry fp32 summation-order differences of the statistics to bf16 level, and ReLU6 / max-pool switches
+        # amplify that in the gradients (DESIGN 7): bars, not equality. Measured: sync 5.0e-2 / 7.9e-5 / 6.2e-4, per-replica
+        # statistics 7.1e-1 / 3.0e-3 / 6.9e-2
+        assert r[True][0] < 1e-1 and r[True][1] < 5e-4 and r[True][2] < 2e-3, (rank, r)
+        assert r[False][0] > 5 * r[True][0], (rank, r)
     assert all(p.exitcode == 0 for p in procs)
