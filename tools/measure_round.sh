@@ -13,6 +13,7 @@ timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format cs
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_w -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-roofline --eager > /dev/null 2> $OUT/pmc_w.err
 F=$(ls $OUT/pmc_f/*counter_collection.csv | head -1); W=$(ls $OUT/pmc_w/*counter_collection.csv | head -1)
 python tools/pmc_traffic.py $F $W gemm_b $OUT/${TAG}_gemm_pmc.json
+python tools/pmc_traffic.py $F $W gemm_big_kernel $OUT/${TAG}_gemm_big_pmc.json
 python tools/pmc_traffic.py $F $W ln_bwd_kernel $OUT/${TAG}_ln_bwd_pmc.json
 rm -rf $OUT/pmc_f $OUT/pmc_w
 cat $OUT/bench.json
