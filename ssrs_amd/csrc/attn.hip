@@ -2,7 +2,7 @@
 // qkv bias) and global, with decomposed relative-position bias, flash-style online softmax.
 // See attn_common.h for the reference semantics (lora_block.py:169-196, 248-317).
 //
-// Workgroup = 4 waves x 16 queries of one (image-modality, head, window); blockIdx.x enumerates only the
+// Workgroup = 4 waves x 16 queries of one (image-modality, head, window); the 1-D grid (att_locate_wg) enumerates only the
 // (window, 64-query tile) pairs that exist. Keys are staged in LDS in chunks of 128: K and V row-major
 // [key][64] (XOR-swizzled 16-B chunks; K fragments by ds_read_b128, V^T fragments by the gfx950 transposing
 // read ds_read_b64_tr_b16 - no transposed image is ever stored).
@@ -34,7 +34,7 @@ struct AttnFwdParams {
 // 4 x 4 patch of the w term that is the same for every tile - and the indicator product (8 of the 12 MFMA k-steps per
 // tile at KH + KW = 128) disappears.
 template <int NSG, int HD, bool ROWT>      // NSG: 32-slot groups of the indicator product, ceil((KH + KW) / 32) rounded up to 1, 2 or 4
-__global__ __launch_bounds__(256, (NSG == 1 && HD <= 64) ? 4 : 2) void attn_fwd_kernel(const AttnFwdParams p) {
+__global__ __launch_bounds__(256, (NSG == 1 && HD <= 64) ? 4 : ((ROWT && HD <= 64) ? 3 : 2)) void attn_fwd_kernel(const AttnFwdParams p) {
   typedef AttHd<HD> H;
   constexpr int KS = H::KS, UT = H::UT, ROWB = H::ROWB, CHS = H::CHS, CHV = H::CHV, RPI = H::RPI, NIT = ATT_KC / H::RPI;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -42,14 +42,15 @@ __global__ __launch_bounds__(256, (NSG == 1 && HD <= 64) ? 4 : 2) void attn_fwd_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int T = g.Sh * g.Sw;
-  const int gi = blockIdx.z, head = blockIdx.y;
+  int gi, head, tile_id;
+  if (!att_locate_wg(g.ntile, g.heads, g.G, &tile_id, &head, &gi)) return;
   int wi, wj, qt0;
-  att_locate_tile(g, blockIdx.x, &wi, &wj, &qt0);
+  att_locate_tile(g, tile_id, &wi, &wj, &qt0);
   const int nq = num_queries(g, wi, wj);
   const int Nk = g.KH * g.KW;
   const int TLD = g.NT + 4;
   const int nsg = (g.KH + g.KW + 31) >> 5;
-  const int regionA = att_region_a(g.NT, ROWB);
+  const int regionA = att_region_a(g.NT, ROWB, ROWT);
 
   unsigned char* K_lds = smem;                                     // [128][64] bf16, swizzled
   unsigned char* V_lds = smem + ATT_KC * ROWB;                     // [128][hd] bf16, swizzled
@@ -88,19 +89,34 @@ __global__ __launch_bounds__(256, (NSG == 1 && HD <= 64) ? 4 : 2) void attn_fwd_
     }
   };
   // ---- T^T = tbl . Q^T  -> T_lds[query][table row], then this lane's slots of T' / scale as bf16 hi + lo
-  float* Trow = T_lds + (wave * 16 + fr) * TLD;
-  att_table_product<HD>(p.tbl, g.NT, qf, Trow, fr, fq);
   bf16x8_t tqh[NSG], tql[NSG];
   float wb[4][4];                                                  // ROWT: bias / scale of this lane's keys 16 t + 4 fq + r (w term)
   float* Thq = (float*)G_lds;                                      // ROWT: [64 queries][KH] h term / scale
   if (ROWT) {
+    // the table is walked 64 rows at a time through the wave's own block buffer; each block hands over the entries it holds
     const float inv = 1.0f / g.scale;
+    float* Tb = T_lds + (wave * 16 + fr) * ATT_TB_LD;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) wb[t][r] = Trow[g.Lh + (g.KW - 1 - (16 * t + 4 * fq + r)) + qp.qw] * inv;
-    for (int j = fq; j < g.KH; j += 4) Thq[(wave * 16 + fr) * g.KH + j] = Trow[(g.KH - 1 - j) + qp.qh] * inv;
+      for (int r = 0; r < 4; ++r) wb[t][r] = 0.f;
+    for (int b0 = 0; b0 < g.NT; b0 += 64) {
+      att_table_block<HD>(p.tbl, g.NT, b0, qf, Tb, fr, fq);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int idx = g.Lh + (g.KW - 1 - (16 * t + 4 * fq + r)) + qp.qw - b0;
+          if (idx >= 0 && idx < 64) wb[t][r] = Tb[idx] * inv;
+        }
+      for (int j = fq; j < g.KH; j += 4) {
+        const int idx = (g.KH - 1 - j) + qp.qh - b0;
+        if (idx >= 0 && idx < 64) Thq[(wave * 16 + fr) * g.KH + j] = Tb[idx] * inv;
+      }
+    }
   } else {
+    float* Trow = T_lds + (wave * 16 + fr) * TLD;
+    att_table_product<HD>(p.tbl, g.NT, qf, Trow, fr, fq);
     att_slot_fragments<NSG>(g, Trow, qp.qh, qp.qw, fq, nsg, tqh, tql);
   }
 
@@ -110,6 +126,8 @@ __global__ __launch_bounds__(256, (NSG == 1 && HD <= 64) ? 4 : 2) void attn_fwd_
 #pragma unroll
   for (int u = 0; u < UT; ++u) o[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+  // (ROWT, 32 chunks per workgroup at 3 workgroups per CU: issuing the next chunk's loads under this chunk's MFMAs measured
+  // no gain - 296 against 298 us - once the table block buffer let three workgroups share a CU)
   for (int kc = 0; kc < Nk; kc += ATT_KC) {
     issue_chunk(kc);
     __syncthreads();   // previous chunk fully consumed (first pass: every wave has read its T rows)
@@ -232,7 +250,9 @@ int attn_fill_geom(AttnGeom* g, int64_t G, int64_t Sh, int64_t Sw, int64_t heads
   return MFNET_OK;
 }
 
+bool attn_row_tiles(const AttnGeom& g);
 static size_t attn_fwd_lds(const AttnGeom& g, int rowb) {
+  if (attn_row_tiles(g)) return (size_t)att_region_a(g.NT, rowb, true) + (size_t)ATT_QT * g.KH * 4;      // K / V + Thq
   return (size_t)att_region_a(g.NT, rowb) + (size_t)((g.KH + g.KW + 31) / 32) * ATT_KC * ATT_GROW;
 }
 
@@ -283,8 +303,10 @@ extern "C" int mfnet_attn_fwd(const void* qkv, const float* qkv_bias, const void
     }
   }
   MF_CHECK_ARG(p.g.KH + p.g.KW <= 128, "attn_fwd: key grid %dx%d too large (KH + KW <= 128)", p.g.KH, p.g.KW);
-  dim3 grid((unsigned)attn_query_tiles(p.g), (unsigned)heads, (unsigned)G);
-  MF_CHECK_ARG(grid.z <= 65535 && grid.y <= 65535, "attn_fwd: grid too large");
+  p.g.ntile = attn_query_tiles(p.g);
+  const int64_t nwg = att_grid(p.g.ntile, heads * G);
+  MF_CHECK_ARG(nwg < (1ll << 31), "attn_fwd: grid too large");
+  dim3 grid((unsigned)nwg);
   MF_CHECK_ARG(lds <= 160 * 1024, "attn_fwd: LDS demand too large");
   const int nsg = (p.g.KH + p.g.KW + 31) / 32;
 #define ATT_FWD(HDV)                                                                                   \

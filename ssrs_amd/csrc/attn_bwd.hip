@@ -39,7 +39,7 @@ struct AttnBwdParams {
 // ROWT (see attn_fwd_kernel): the bias enters as the initial accumulator; its gradient needs no indicator product either -
 // the w part is the lane's own 4 x 4 patch of dS summed over the tiles, the h part one per-query sum of dS per tile.
 template <int NSG, int HD, bool ROWT>
-__global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : 2)) void attn_bwd_dq_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(256, HD > 64 ? 1 : ((NSG == 1 || ROWT) ? 3 : 2)) void attn_bwd_dq_kernel(const AttnBwdParams p) {
   typedef AttHd<HD> H;
   constexpr int KS = H::KS, UT = H::UT, ROWB = H::ROWB, CHS = H::CHS, CHV = H::CHV, RPI = H::RPI, NIT = ATT_KC / H::RPI;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -47,9 +47,10 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : 2)) void attn_bw
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int T = g.Sh * g.Sw;
-  const int gi = blockIdx.z, head = blockIdx.y;
+  int gi, head, tile_id;
+  if (!att_locate_wg(g.ntile, g.heads, g.G, &tile_id, &head, &gi)) return;
   int wi, wj, qt0;
-  att_locate_tile(g, blockIdx.x, &wi, &wj, &qt0);
+  att_locate_tile(g, tile_id, &wi, &wj, &qt0);
   const int nq = num_queries(g, wi, wj);
   const int Nk = g.KH * g.KW;
   const int TLD = g.NT + 4;
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : 2)) void attn_bw
   unsigned char* K_lds = smem;                                        // [128][64] swizzled
   unsigned char* V_lds = smem + ATT_KC * ROWB;                        // [128][hd] swizzled
   float* T_lds = (float*)smem;                                        // [64][NT+4] before the key loop; dT after it
-  unsigned char* G_lds = smem + att_region_a(g.NT, ROWB);             // [nsg][128][32] bf16 indicator rows
+  unsigned char* G_lds = smem + att_region_a(g.NT, ROWB, ROWT);       // [nsg][128][32] bf16 indicator rows
 
   const int64_t row_base = (int64_t)gi * T;
   const int ld = 3 * g.D;                                          // (one image's qkv rows span < 2^31 elements)
@@ -85,27 +86,46 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : 2)) void attn_bw
     delta += __shfl_xor(delta, 32, 64);
   }
   // T^T = tbl . Q^T -> T_lds, then this lane's slots of T' / scale (attn.hip)
-  float* Trow = T_lds + (wave * 16 + fr) * TLD;
-  att_table_product<HD>(p.tbl, g.NT, qf, Trow, fr, fq);
   bf16x8_t tqh[NSG], tql[NSG];
   float wb[4][4], dwb[4][4];                                          // ROWT: w-term bias / scale of this lane's keys, and its gradient
   float* Thq = (float*)G_lds;                                         // ROWT: [64 queries][KH] h term / scale
-  float* dThq = Thq + ATT_QT * 64;                                    // ROWT: [64 queries][KH] its gradient (one tile = one key row)
+  float* dThq = Thq;                                                  // ROWT: its gradient, IN PLACE: a tile is one key row, visited once per query -
+                                                                      // entry [q][row] is read (hb) before the same wave overwrites it with the row's dS sum
+  float* Tb = T_lds + (wave * 16 + fr) * ATT_TB_LD;                   // ROWT: this lane's query row of the wave's 64-row table block
   if (ROWT) {
+    // the table is walked 64 rows at a time through the wave's own block buffer (attn.hip)
     const float inv = 1.0f / g.scale;
+    float* wr = p.bias_ws + (((int64_t)gi * g.heads + head) * T + qp.tok) * ATT_WS_LD;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { wb[t][r] = Trow[g.Lh + (g.KW - 1 - (16 * t + 4 * fq + r)) + qp.qw] * inv; dwb[t][r] = 0.f; }
-    for (int j = fq; j < g.KH; j += 4) Thq[(wave * 16 + fr) * g.KH + j] = Trow[(g.KH - 1 - j) + qp.qh] * inv;
-    if (qp.valid) {                   // the dK/dV kernel reads these rows instead of repeating the table product per key tile
-      float* wr = p.bias_ws + (((int64_t)gi * g.heads + head) * T + qp.tok) * ATT_WS_LD;
-      for (int j = fq; j < g.KH; j += 4) wr[j] = Trow[(g.KH - 1 - j) + qp.qh] * inv;
+      for (int r = 0; r < 4; ++r) { wb[t][r] = 0.f; dwb[t][r] = 0.f; }
+    for (int b0 = 0; b0 < g.NT; b0 += 64) {
+      att_table_block<HD>(p.tbl, g.NT, b0, qf, Tb, fr, fq);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int idx = g.Lh + (g.KW - 1 - (16 * t + 4 * fq + r)) + qp.qw - b0;
+          if (idx >= 0 && idx < 64) wb[t][r] = Tb[idx] * inv;
+        }
+      for (int j = fq; j < g.KH; j += 4) {
+        const int idx = (g.KH - 1 - j) + qp.qh - b0;
+        if (idx >= 0 && idx < 64) {
+          const float v = Tb[idx] * inv;
+          Thq[(wave * 16 + fr) * g.KH + j] = v;
+          if (qp.valid) wr[j] = v;    // the dK/dV kernel reads these rows instead of repeating the table product per key tile
+        }
+      }
+    }
+    if (qp.valid) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
         *reinterpret_cast<float4*>(wr + g.KH + 16 * t + 4 * fq) = make_float4(wb[t][0], wb[t][1], wb[t][2], wb[t][3]);
     }
   } else {
+    float* Trow = T_lds + (wave * 16 + fr) * TLD;
+    att_table_product<HD>(p.tbl, g.NT, qf, Trow, fr, fq);
     att_slot_fragments<NSG>(g, Trow, qp.qh, qp.qw, fq, nsg, tqh, tql);
     if (qp.valid) {                   // the dK/dV kernel reads the query's slot rows (hi, lo) instead of recomputing them per key tile
       unsigned char* wr = (unsigned char*)p.bias_ws + (((int64_t)gi * g.heads + head) * T + qp.tok) * (int64_t)(nsg * 128);
@@ -128,10 +148,10 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : 2)) void attn_bw
   const int ch = tid % CHS, chl = ch < CHV ? ch : CHV - 1;   // this thread always stages 16-B chunk slot `ch` of a key row
   const PaddedKV pad = att_padded_kv(p.qkv_bias, g.D, head, HD, chl);
 
-  for (int kc = 0; kc < Nk; kc += ATT_KC) {
-    // all global loads of the chunk first, unconditionally (see attn_fwd_kernel)
-    u32x4_t kv[NIT], vv[NIT];
-    int kkind[NIT];
+  // all global loads of a chunk first, unconditionally (see attn_fwd_kernel)
+  u32x4_t kv[NIT], vv[NIT];
+  int kkind[NIT];
+  auto issue_chunk = [&](int kc) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int kg = kc + it * RPI + tid / CHS;
@@ -142,6 +162,9 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : 2)) void attn_bw
       vv[it] = *reinterpret_cast<const u32x4_t*>(src + g.D);
       kkind[it] = ch >= CHV ? 2 : (tok < 0 ? (tok == -2 ? 2 : 1) : 0);
     }
+  };
+  for (int kc = 0; kc < Nk; kc += ATT_KC) {
+    issue_chunk(kc);
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -234,43 +257,71 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : 2)) void attn_bw
     }
   }
   __syncthreads();   // K / V images dead: their LDS becomes dT
-  float* dTrow = T_lds + (wave * 16 + fr) * TLD;
 #pragma unroll
   for (int u = 0; u < UT; ++u) { dq[u][0] *= g.scale; dq[u][1] *= g.scale; dq[u][2] *= g.scale; dq[u][3] *= g.scale; }
-  for (int t = 0; t < g.NT / 16; ++t) *reinterpret_cast<float4*>(dTrow + 16 * t + 4 * fq) = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
-  // dT[q][j + qh] = dT'[q][j] (j < KH) ; dT[q][Lh + j' + qw] = dT'[q][KH + j'] : one lane per (q, slot), plain stores
   if (ROWT) {
+    // dQ^T += tbl^T . dT^T, 64 table rows at a time through the wave's block buffer: zero it, drop in the entries of dT that fall
+    // into the block (dT[q][(KH-1-j) + qh] = dThq[q][j]; dT[q][Lh + (KW-1-kw) + qw] = dwb of key column kw), multiply
     if (wave_active) {
-      for (int j = fq; j < g.KH; j += 4) dTrow[(g.KH - 1 - j) + qp.qh] = dThq[(wave * 16 + fr) * g.KH + j];
+      for (int b0 = 0; b0 < g.NT; b0 += 64) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(Tb + 16 * fq + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = fq; j < g.KH; j += 4) {
+          const int idx = (g.KH - 1 - j) + qp.qh - b0;
+          if (idx >= 0 && idx < 64) Tb[idx] = dThq[(wave * 16 + fr) * g.KH + j];
+        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dTrow[g.Lh + (g.KW - 1 - (16 * t + 4 * fq + r)) + qp.qw] = dwb[t][r];
-    }
-  } else
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-  for (int c = 0; c < NSG; ++c)
+          for (int r = 0; r < 4; ++r) {
+            const int idx = g.Lh + (g.KW - 1 - (16 * t + 4 * fq + r)) + qp.qw - b0;
+            if (idx >= 0 && idx < 64) Tb[idx] = dwb[t][r];
+          }
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+        for (int s3 = 0; s3 < 2; ++s3) {
+          if (b0 + 32 * s3 < g.NT) {
+            const float4 d0 = *reinterpret_cast<const float4*>(Tb + 32 * s3 + 8 * fq);
+            const float4 d1 = *reinterpret_cast<const float4*>(Tb + 32 * s3 + 8 * fq + 4);
+            union { bf16x8_t v; unsigned int w[4]; } bf;
+            bf.w[0] = pack_bf16x2(d0.x, d0.y); bf.w[1] = pack_bf16x2(d0.z, d0.w);
+            bf.w[2] = pack_bf16x2(d1.x, d1.y); bf.w[3] = pack_bf16x2(d1.z, d1.w);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = 32 * c + 16 * u + 4 * fq + r;
-        if (j < g.KH) dTrow[j + qp.qh] = dgt[c][u][r];
-        else if (j < g.KH + g.KW) dTrow[g.Lh + (j - g.KH) + qp.qw] = dgt[c][u][r];
+            for (int u = 0; u < UT; ++u) {
+              const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(p.tblT + (int64_t)(16 * u + fr) * g.NT + b0 + 32 * s3 + 8 * fq);
+              dq[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf.v, dq[u], 0, 0, 0);
+            }
+          }
+        }
       }
-  __syncthreads();
-  // dQ^T += tbl^T . dT^T
-  for (int s3 = 0; s3 < g.NT / 32; ++s3) {
-    const float4 d0 = *reinterpret_cast<const float4*>(dTrow + 32 * s3 + 8 * fq);
-    const float4 d1 = *reinterpret_cast<const float4*>(dTrow + 32 * s3 + 8 * fq + 4);
-    union { bf16x8_t v; unsigned int w[4]; } bf;
-    bf.w[0] = pack_bf16x2(d0.x, d0.y); bf.w[1] = pack_bf16x2(d0.z, d0.w);
-    bf.w[2] = pack_bf16x2(d1.x, d1.y); bf.w[3] = pack_bf16x2(d1.z, d1.w);
+    }
+  } else {
+    float* dTrow = T_lds + (wave * 16 + fr) * TLD;
+    for (int t = 0; t < g.NT / 16; ++t) *reinterpret_cast<float4*>(dTrow + 16 * t + 4 * fq) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    // dT[q][j + qh] = dT'[q][j] (j < KH) ; dT[q][Lh + j' + qw] = dT'[q][KH + j'] : one lane per (q, slot), plain stores
 #pragma unroll
-    for (int u = 0; u < UT; ++u) {
-      const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(p.tblT + (int64_t)(16 * u + fr) * g.NT + 32 * s3 + 8 * fq);
-      dq[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf.v, dq[u], 0, 0, 0);
+    for (int c = 0; c < NSG; ++c)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 32 * c + 16 * u + 4 * fq + r;
+          if (j < g.KH) dTrow[j + qp.qh] = dgt[c][u][r];
+          else if (j < g.KH + g.KW) dTrow[g.Lh + (j - g.KH) + qp.qw] = dgt[c][u][r];
+        }
+    __syncthreads();
+    // dQ^T += tbl^T . dT^T
+    for (int s3 = 0; s3 < g.NT / 32; ++s3) {
+      const float4 d0 = *reinterpret_cast<const float4*>(dTrow + 32 * s3 + 8 * fq);
+      const float4 d1 = *reinterpret_cast<const float4*>(dTrow + 32 * s3 + 8 * fq + 4);
+      union { bf16x8_t v; unsigned int w[4]; } bf;
+      bf.w[0] = pack_bf16x2(d0.x, d0.y); bf.w[1] = pack_bf16x2(d0.z, d0.w);
+      bf.w[2] = pack_bf16x2(d1.x, d1.y); bf.w[3] = pack_bf16x2(d1.z, d1.w);
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(p.tblT + (int64_t)(16 * u + fr) * g.NT + 32 * s3 + 8 * fq);
+        dq[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf.v, dq[u], 0, 0, 0);
+      }
     }
   }
   if (qp.valid) {
@@ -295,7 +346,7 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 3 : 2)) void attn_bw
 // rows x 16 key columns a wave reads at once), instead of the T'.G^T indicator product.
 #define ATT_TS 68
 template <int NSG, int HD, bool ROWT>
-__global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 4 : (NSG == 4 ? 2 : 3))) void attn_bwd_dkv_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 4 : ((NSG == 4 && !ROWT) ? 2 : 3))) void attn_bwd_dkv_kernel(const AttnBwdParams p) {
   typedef AttHd<HD> H;
   constexpr int KS = H::KS, UT = H::UT, ROWB = H::ROWB, CHS = H::CHS, CHV = H::CHV, RPI = H::RPI, NIT = ATT_QT / H::RPI;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -303,9 +354,10 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : (NSG == 1 ? 4 : (NSG == 4 ? 2 : 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int T = g.Sh * g.Sw;
-  const int gi = blockIdx.z, head = blockIdx.y;
+  int gi, head, tile_id;
+  if (!att_locate_wg(g.ntile, g.heads, g.G, &tile_id, &head, &gi)) return;
   int wi, wj, k0;
-  att_locate_tile(g, blockIdx.x, &wi, &wj, &k0);
+  att_locate_tile(g, tile_id, &wi, &wj, &k0);
   const int nq = num_queries(g, wi, wj);      // real keys of a window == its real queries
   const int nsg = (g.KH + g.KW + 31) >> 5;
 
@@ -542,16 +594,19 @@ extern "C" int mfnet_attn_bwd(const void* qkv, const float* qkv_bias, const void
   }
   const int nsg = (p.g.KH + p.g.KW + 31) / 32;
   const int rowb = hd <= 64 ? AttHd<64>::ROWB : AttHd<80>::ROWB;
-  const size_t lds_dq = (size_t)att_region_a(p.g.NT, rowb) + (size_t)nsg * ATT_KC * ATT_GROW;
   const bool rowt = attn_row_tiles(p.g);
+  const size_t lds_dq = rowt ? (size_t)att_region_a(p.g.NT, rowb, true) + (size_t)ATT_QT * p.g.KH * 4            // K / V + Thq (dThq in place)
+                             : (size_t)att_region_a(p.g.NT, rowb) + (size_t)nsg * ATT_KC * ATT_GROW;
   MF_CHECK_ARG(workspace && workspace_floats >= mfnet_attn_bwd_workspace_floats(G, Sh, Sw, heads, ws) && (uintptr_t)workspace % 16 == 0,
                "attn_bwd: needs a 16-byte aligned workspace of mfnet_attn_bwd_workspace_floats(G, Sh, Sw, heads, ws) floats");
   p.bias_ws = workspace;
   const size_t lds_dkv = 2 * (size_t)ATT_QT * rowb + 2 * ATT_QT * 4 + 2 * (rowt ? (size_t)ATT_QT * ATT_TS * 4 : (size_t)nsg * ATT_QT * ATT_GROW);
   MF_CHECK_ARG(lds_dq <= 160 * 1024 && lds_dkv <= 160 * 1024, "attn_bwd: LDS demand too large");
   // the two kernels write disjoint column ranges of dqkv (q | k,v); window mode leaves nothing unwritten
-  dim3 grid_q((unsigned)attn_query_tiles(p.g), (unsigned)heads, (unsigned)G);
-  MF_CHECK_ARG(grid_q.z <= 65535 && grid_q.y <= 65535, "attn_bwd: grid too large");
+  p.g.ntile = attn_query_tiles(p.g);
+  const int64_t nwg = att_grid(p.g.ntile, heads * G);
+  MF_CHECK_ARG(nwg < (1ll << 31), "attn_bwd: grid too large");
+  dim3 grid_q((unsigned)nwg);
 #define ATT_BWD(KERNEL, LDS, HDV)                                                                          \
   do {                                                                                                     \
     if (rowt) hipLaunchKernelGGL((KERNEL<4, HDV, true>), grid_q, dim3(256), LDS, stream, p);               \

@@ -32,6 +32,7 @@ template <int HD> struct AttHd {
 #define ATT_VT_LD (ATT_KC + 8)   // bf16 elements per row of the transposed [hd][key] images
 
 struct AttnGeom {
+  int ntile;                 // (window, 64-row tile) pairs per image = attn_query_tiles
   int G, Sh, Sw, heads, D;   // G = image-modalities, token grid Sh x Sw, D = heads*64
   int ws;                    // 0 = global attention
   int nWh, nWw;              // windows per axis (1,1 for global)
@@ -79,9 +80,12 @@ __device__ __forceinline__ int gswz(int row) { return (row >> 2) & 3; }   // sam
 
 #define ATT_GROW 64        // bytes per key row of one 32-slot indicator image
 
-// LDS bytes shared by the K / V images (key loop) and the T table (before it)
-__host__ __device__ inline int att_region_a(int NT, int rowb) {
-  const int kv = 2 * ATT_KC * rowb, t = ATT_QT * (NT + 4) * 4;
+// LDS bytes shared by the K / V images (key loop) and the T table (before it). ROWT kernels walk the table in blocks of
+// 64 rows through a wave-private [16][ATT_TB_LD] buffer (att_table_block) instead of holding all NT rows of 64 queries:
+// at NT = 256 the whole table is 66 KB and left ONE workgroup per CU.
+#define ATT_TB_LD 68
+__host__ __device__ inline int att_region_a(int NT, int rowb, bool rowt = false) {
+  const int kv = 2 * ATT_KC * rowb, t = rowt ? ATT_QT * ATT_TB_LD * 4 : ATT_QT * (NT + 4) * 4;
   return kv > t ? kv : t;
 }
 
@@ -90,7 +94,22 @@ __device__ __forceinline__ s16x4_t att_tr_read(const unsigned char* lds_addr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(lds_addr));
 }
 
-// blockIdx.x -> (window, first query) over the (window, 64-query tile) pairs that exist
+// XCD-aware placement of the workgroups of a 1-D grid: the hardware deals consecutive workgroup ids round-robin to the 8
+// XCDs, each with its own L2. All `nt` tiles of one (image-modality, head) pair read the same K / V (or Q / dO / bias) rows, so
+// pair p goes to XCD p % 8 whole: id = 8 * s + x runs tile s % nt of pair x + 8 * (s / nt). (With (tile, head, image) as the
+// grid axes a pair's tiles were spread over all XCDs: every L2 fetched every pair's rows - at 64 x 64 tokens the dK/dV kernel
+// pulled 8.5 TB/s through the fabric.) Grid: att_grid(nt, pairs) workgroups; ids past the last pair of an XCD return at once.
+__device__ __forceinline__ bool att_locate_wg(int nt, int heads, int G, int* tile, int* head, int* gi) {
+  const int id = blockIdx.x, x = id & 7, s = id >> 3;
+  const int pr = s / nt, p = x + 8 * pr;
+  if (p >= heads * G) return false;
+  *tile = s - pr * nt;
+  *gi = p / heads; *head = p - *gi * heads;
+  return true;
+}
+static inline int64_t att_grid(int64_t nt, int64_t pairs) { return 8 * nt * ((pairs + 7) / 8); }
+
+// tile index -> (window, first query) over the (window, 64-query tile) pairs that exist
 __device__ __forceinline__ void att_locate_tile(const AttnGeom& g, int t, int* wi, int* wj, int* qt0) {
   int i = 0, j = 0;
   for (int w = 0; w + 1 < g.nWh * g.nWw; ++w) {       // (the last window takes what is left)
@@ -129,6 +148,31 @@ __device__ __forceinline__ void att_table_product(const bf16_t* tbl, int NT, con
         for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], qf[ks], acc, 0, 0, 0);
         *reinterpret_cast<float4*>(Trow + 16 * (t0 + i) + 4 * fq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
       }
+    }
+  }
+}
+
+// Rows [b0, b0 + 64) of T^T = tbl . Q^T for this wave's 16 queries -> Tb[row - b0] (Tb: this lane's query row of the wave's
+// [16][ATT_TB_LD] block buffer). Written and read by the same wave only (LDS serves a wave's accesses in order).
+template <int HD>
+__device__ __forceinline__ void att_table_block(const bf16_t* tbl, int NT, int b0, const bf16x8_t (&qf)[AttHd<HD>::KS], float* Tb, int fr, int fq) {
+  constexpr int KS = AttHd<HD>::KS, HDP = AttHd<HD>::HDP;
+  const int nt16 = NT >> 4, t0 = b0 >> 4;
+  bf16x8_t a[4][KS];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = min(t0 + i, nt16 - 1);
+    const bf16_t* tp = tbl + (int64_t)(16 * t + fr) * HDP + 8 * fq;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a[i][ks] = *reinterpret_cast<const bf16x8_t*>(tp + 32 * ks);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (t0 + i < nt16) {
+      f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], qf[ks], acc, 0, 0, 0);
+      *reinterpret_cast<float4*>(Tb + 16 * i + 4 * fq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
   }
 }
