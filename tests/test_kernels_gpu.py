@@ -746,3 +746,20 @@ def test_conv3x3_rejects_bad_geometry(ops):
     w = torch.zeros(16, 9 * 32, device="cuda", dtype=torch.bfloat16)
     with pytest.raises(MfnetError):
         ops.conv3x3(x, w, 1, 8, 8)                     # channels not a multiple of 64
+
+
+@pytest.mark.parametrize("n,h,w", [(32, 256, 256), (3, 10, 10), (2, 7, 1), (1, 300, 300)])
+def test_tile_minmax_norm(ops, n, h, w):
+    """per-tile DSM min-max (inference.py:547-555; multiscale_dataset.py:205-208 with keep_flat): the register-resident kernel
+    (tiles up to 65536 values) and the two-pass one give the bits of the fp32 statement; a flat tile becomes 0 / stays."""
+    x = rnd(n, h, w, seed=11, scale=30.0)
+    x[0] = 4.25                                              # a flat tile
+    for keep in (False, True):
+        y = x.clone()
+        ops.tile_minmax_norm(y, keep_flat=keep)
+        lo = x.amin(dim=(1, 2), keepdim=True)
+        rng = x.amax(dim=(1, 2), keepdim=True) - lo
+        ref = torch.where(rng > 0, (x - lo) / rng, torch.zeros_like(x))
+        if keep:
+            ref[0] = x[0]
+        assert torch.equal(y, ref)
