@@ -18,6 +18,7 @@
 // fragments (NF = 6 -> 4 + 2, 9 -> 4 + 4 + 1, 3 -> 2 + 1) and inside a group lane quarter fq owns columns 4G*fq .. 4G*fq+4G-1,
 // so bias / aux / residual loads and the stores are 16-byte (G >= 2) or 8-byte (G = 1, bf16) accesses.
 #include "gemm_params.h"
+#include <type_traits>
 
 #define BIG_BM 256
 #define BIG_BK 64
@@ -166,6 +167,19 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
       }
       __builtin_amdgcn_sched_group_barrier(0x008, NM - PER * NR > 0 ? NM - PER * NR : 0, 0);
     };
+    // the same with the PPW global_load_lds of the ring's next tile dealt out one per read slot: issued in one burst behind the
+    // barrier, the 8 waves' ~50 requests fill the CU's vector-memory queue together and every wave's MFMAs wait in program order
+    // behind its own third to sixth request
+    auto weave_v = [&]() {
+      constexpr int NR = 4 + NF, NM = 4 * (NF - 1), PER = NM / NR > 0 ? NM / NR : 1;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (i < C::PPW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NM - PER * NR > 0 ? NM - PER * NR : 0, 0);
+    };
     // tile 0 landed: at most the younger tiles of this wave outstanding
     if (nt >= C::STAGES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PPW * (C::STAGES - 1)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -176,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
     // (in each half the first MFMAs go ahead of the next reads: hipcc's wait for fragments whose reads crossed a loop edge or
     // an asm statement is lgkmcnt(0) - it must not cover the reads just issued; the last tile is peeled so that no branch
     // joins inside the body)
-    for (int t = 0; t + 1 < nt; ++t) {
+    auto body = [&](auto with_stage, int t) {
       const unsigned char* base = lds + (t % C::STAGES) * C::STAGE_BYTES;
       mm(xa, wa, 0, 1);
       __builtin_amdgcn_sched_barrier(0);
@@ -193,14 +207,31 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
 #endif
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (t + C::STAGES < nt) stage(t + C::STAGES, t % C::STAGES);
-      __builtin_amdgcn_sched_barrier(0);
       mm(xb, wb, 0, 1);
       __builtin_amdgcn_sched_barrier(0);
-      rd(lds + ((t + 1) % C::STAGES) * C::STAGE_BYTES, 0, xa, wa);
+      if constexpr (decltype(with_stage)::value) {
+        // fragment reads and ring requests alternate in program order: the compiler keeps LDS reads and LDS-DMA writes in the
+        // order it finds them (it cannot tell the two stage buffers apart)
+        const unsigned char* nb = lds + ((t + 1) % C::STAGES) * C::STAGE_BYTES;
+        unsigned char* sb = lds + (t % C::STAGES) * C::STAGE_BYTES;
+        const int kt = t + C::STAGES;
+#pragma unroll
+        for (int i = 0; i < 4 + NF || i < C::PPW; ++i) {
+          if (i < 4) xa[i] = *reinterpret_cast<const bf16x8_t*>(nb + x_off[i] + ((fq ^ x_sw[i]) << 4));
+          else if (i < 4 + NF) wa[i - 4] = *reinterpret_cast<const bf16x8_t*>(nb + w_off[i - 4] + ((fq ^ w_sw[i - 4]) << 4));
+          if (i < C::PPW) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[i] + kt * BIG_BK), (lds_ptr_t)(sb + dst_off[i]), 16, 0, 0);
+        }
+      } else {
+        rd(lds + ((t + 1) % C::STAGES) * C::STAGE_BYTES, 0, xa, wa);
+      }
       mm(xb, wb, 1, NF);
-      weave();
+      if constexpr (decltype(with_stage)::value) weave_v(); else weave();
       __builtin_amdgcn_sched_barrier(0);
+    };
+    {
+      int t = 0;
+      for (; t + C::STAGES < nt; ++t) body(std::true_type{}, t);       // the ring's next tile exists
+      for (; t + 1 < nt; ++t) body(std::false_type{}, t);
     }
     mm(xa, wa, 0, 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -213,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
 #pragma unroll
     for (int s = 0; s < C::STAGES - 1; ++s)
       if (s < nt) stage(s, s);
-    for (int t = 0; t < nt; ++t) {
+    auto body = [&](auto with_stage, int t) {
       // tile t has landed once at most the (STAGES-2) younger tiles of this wave are outstanding (vmcnt counts in issue order)
       if (C::STAGES == 3 && t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PPW) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -222,7 +253,6 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
 #ifdef GEMM_STAMPS
       if (t == 0) MF_STAMP(1);
 #endif
-      if (t + C::STAGES - 1 < nt) stage(t + C::STAGES - 1, (t + C::STAGES - 1) % C::STAGES);
       const unsigned char* base = lds + (t % C::STAGES) * C::STAGE_BYTES;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -232,12 +262,30 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
         for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8_t*>(base + x_off[i] + ((ch ^ x_sw[i]) << 4));
 #pragma unroll
         for (int f = 0; f < NF; ++f) wf[f] = *reinterpret_cast<const bf16x8_t*>(base + w_off[f] + ((ch ^ w_sw[f]) << 4));
+        // the ring's next tile is requested piece by piece between the MFMAs of the first k-step (one burst of PPW requests
+        // per wave behind the barrier fills the CU's vector-memory queue and holds the MFMAs behind it in program order)
+        if (decltype(with_stage)::value && ks == 0) stage(t + C::STAGES - 1, (t + C::STAGES - 1) % C::STAGES);
 #pragma unroll
         for (int f = 0; f < NF; ++f)
 #pragma unroll
           for (int mi = 0; mi < 4; ++mi)
             acc[f][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f], xf[mi], acc[f][mi], 0, 0, 0);
+        if (decltype(with_stage)::value && ks == 0) {
+          constexpr int PERV = (4 * NF) / (C::PPW + 1) > 0 ? (4 * NF) / (C::PPW + 1) : 1;
+#pragma unroll
+          for (int i = 0; i < C::PPW; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, PERV, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 4 * NF - PERV * C::PPW, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
+    };
+    {
+      int t = 0;
+      for (; t + C::STAGES - 1 < nt; ++t) body(std::true_type{}, t);
+      for (; t < nt; ++t) body(std::false_type{}, t);
     }
   }
 
