@@ -382,8 +382,9 @@ class Trainer:
                  training: Optional[TrainingConfig] = None, epochs: int = 50, save_epoch: int = 1,
                  ignore_index: int = -100, skip_empty: bool = False, output_dir: str = "./results/",
                  model_name: str = "UNetformer", sync_every: int = 10, validate_fn=None, val_samples=None, test_ids=None,
-                 val_stride: int = 32, use_graph: bool = True):
-        """use_graph: the engine replays zero_grad + forward + loss + backward from a HIP graph per batch shape (11.7 instead of
+                 val_stride: int = 32, use_graph: bool = True, sync_bn: bool = False):
+        """sync_bn: BatchNorm batch statistics over the whole data-parallel group (TrainEngine; eager steps, so it turns use_graph off).
+        use_graph: the engine replays zero_grad + forward + loss + backward from a HIP graph per batch shape (11.7 instead of
         19.0 ms per ViT-B MMLoRA step of 16 tiles: enqueued eagerly the ~640 launches of a step are host-bound). One graph per
         distinct batch shape (a shorter last batch captures its own); pass False for loaders whose shapes keep changing."""
         self.model_wrapper = model_wrapper
@@ -407,7 +408,7 @@ class Trainer:
         w = torch.ones(t.n_classes, device=dev) if ignore_index == -100 else None
         self.engine = TrainEngine(self.model, lr=t.base_lr, momentum=t.momentum, weight_decay=t.weight_decay,
                                   milestones=t.scheduler_milestones, gamma=t.scheduler_gamma, class_weight=w,
-                                  ignore_index=ignore_index, use_graph=use_graph)
+                                  ignore_index=ignore_index, use_graph=use_graph and not sync_bn, sync_bn=sync_bn)
         self.losses: List[float] = []
         self.recent_losses: List[float] = []
         self.recent_accuracies: List[float] = []
