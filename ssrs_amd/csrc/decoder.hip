@@ -696,6 +696,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const void* __rest
   }
 }
 // dw[c, tap] += sum_pixels dy[pix, c] * x_ext[pix + tap - pad, c]; thread = (tap slot, channel group); block = chunk of pixels
+#define DW_PU 4
 template <bool DY_BF16>      // the gradient's dtype is a template argument: a runtime switch around each load put a branch and a
                              // full memory wait between the loads of one iteration
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const void* __restrict__ dy, int dy_dt, const float* __restrict__ x,
@@ -710,16 +711,16 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const void* __re
   for (int tap = slot; tap < kk; tap += nslot) {
     const int ky = tap / p.k, kx = tap - ky * p.k;
     float4 acc = F4ZERO, bacc = F4ZERO;
-    // four pixels per iteration, their eight loads issued together (unconditionally: a pixel past the chunk or a tap
+    // DW_PU pixels per iteration, their 2 * DW_PU loads issued together (unconditionally: a pixel past the chunk or a tap
     // that falls into the zero padding reads element 0 and is masked): the loop was one dependent round trip per pixel
     // pixel coordinates advance by increments: the three 64-bit divisions per pixel this loop started with were most of its time
     int xx = (int)(p0 % p.W), yy = (int)((p0 / p.W) % p.H);
     int64_t rowb = (p0 / p.W) - yy;                  // b * H
-    for (int64_t pix = p0; pix < p1; pix += 4) {
-      float4 d[4], xv[4];
-      bool ok[4];
+    for (int64_t pix = p0; pix < p1; pix += DW_PU) {
+      float4 d[DW_PU], xv[DW_PU];
+      bool ok[DW_PU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < DW_PU; ++u) {
         const bool in = pix + u < p1;
         const int sy = ext_map(yy + ky - p.pad, p.H, p.ext), sx = ext_map(xx + kx - p.pad, p.W, p.ext);
         ok[u] = in && sy >= 0 && sx >= 0;
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const void* __re
         if (++xx == p.W) { xx = 0; if (++yy == p.H) { yy = 0; rowb += p.H; } }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < DW_PU; ++u) {
         if (tap == 0) bacc = f4add(bacc, d[u]);
         if (ok[u]) acc = f4fma(d[u], xv[u], acc);
       }
@@ -748,6 +749,70 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const void* __re
     if (dbias && tap == 0) {
       float* ob = dbias + (int64_t)sl * p.C;
       atomicAdd(ob + 4 * cg, bacc.x); atomicAdd(ob + 4 * cg + 1, bacc.y); atomicAdd(ob + 4 * cg + 2, bacc.z); atomicAdd(ob + 4 * cg + 3, bacc.w);
+    }
+  }
+}
+// K = 3 / 8: thread = (pixel slot, channel group) instead of (tap slot, channel group). Above, every tap slot streams the whole
+// chunk of dy again (k*k reads of dy and of x per pixel: 0.5 GB through L2 for the 8x8 kernel on the 32x32 maps, 59 us); here a
+// thread reads dy of a pixel once per pass of TG taps (one kernel row for K = 8, all nine taps for K = 3), holds TG float4
+// sums, and the 256 / C4 pixel slots of the workgroup meet in LDS before the (unchanged number of) atomics.
+template <bool DY_BF16, int K>
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_px_kernel(const void* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
+                                                                   float* __restrict__ dbias, const DwParams p, int64_t pix_per_block, int slots) {
+  constexpr int TG = K == 3 ? 9 : K, NPASS = K * K / TG;
+  __shared__ float4 red[(TG + 1) * 256];                    // [tap of the pass | bias][pixel slot][channel group]
+  const int C4 = p.C >> 2, kk = K * K;
+  const int cg = threadIdx.x % C4, ps = threadIdx.x / C4, nps = 256 / C4;
+  const int64_t npix = (int64_t)p.B * p.H * p.W;
+  const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+  int64_t p1 = p0 + pix_per_block;
+  if (p1 > npix) p1 = npix;
+  const int sl = blockIdx.x % slots;
+  for (int pass = 0; pass < NPASS; ++pass) {
+    float4 acc[TG], bacc = F4ZERO;
+#pragma unroll
+    for (int t = 0; t < TG; ++t) acc[t] = F4ZERO;
+    for (int64_t pix = p0 + ps; pix < p1; pix += nps) {
+      const int xx = (int)(pix % p.W), yy = (int)((pix / p.W) % p.H);
+      const int64_t rowb = (pix / p.W) - yy;               // b * H
+      float4 d;
+      if (DY_BF16) {
+        const u32x2_t w2 = reinterpret_cast<const u32x2_t*>(dy)[pix * C4 + cg];
+        d = make_float4(bf16_lo(w2.x), bf16_hi(w2.x), bf16_lo(w2.y), bf16_hi(w2.y));
+      } else {
+        d = reinterpret_cast<const float4*>(dy)[pix * C4 + cg];
+      }
+      float4 xv[TG];
+      bool ok[TG];
+#pragma unroll
+      for (int t = 0; t < TG; ++t) {
+        const int tap = pass * TG + t, ky = tap / K, kx = tap - ky * K;
+        const int sy = ext_map(yy + ky - p.pad, p.H, p.ext), sx = ext_map(xx + kx - p.pad, p.W, p.ext);
+        ok[t] = sy >= 0 && sx >= 0;
+        xv[t] = reinterpret_cast<const float4*>(x)[ok[t] ? ((rowb + sy) * p.W + sx) * C4 + cg : cg];
+      }
+#pragma unroll
+      for (int t = 0; t < TG; ++t)
+        if (ok[t]) acc[t] = f4fma(d, xv[t], acc[t]);
+      if (pass == 0) bacc = f4add(bacc, d);
+    }
+    __syncthreads();                                        // (the previous pass's sums have been read)
+#pragma unroll
+    for (int t = 0; t < TG; ++t) red[t * 256 + threadIdx.x] = acc[t];
+    if (pass == 0) red[TG * 256 + threadIdx.x] = bacc;
+    __syncthreads();
+    // thread -> (entry e of the pass, channel group): sums the pixel slots in a fixed order
+    const int nent = TG + ((pass == 0 && dbias) ? 1 : 0);
+    for (int e = ps; e < nent; e += nps) {
+      float4 v = F4ZERO;
+      for (int q = 0; q < nps; ++q) v = f4add(v, red[e * 256 + q * C4 + cg]);
+      if (e < TG) {
+        float* o = dw + ((int64_t)sl * p.C + 4 * cg) * kk + pass * TG + e;
+        atomicAdd(o, v.x); atomicAdd(o + kk, v.y); atomicAdd(o + 2 * kk, v.z); atomicAdd(o + 3 * kk, v.w);
+      } else {
+        float* ob = dbias + (int64_t)sl * p.C + 4 * cg;
+        atomicAdd(ob, v.x); atomicAdd(ob + 1, v.y); atomicAdd(ob + 2, v.z); atomicAdd(ob + 3, v.w);
+      }
     }
   }
 }
@@ -799,7 +864,15 @@ extern "C" int mfnet_dwconv_bwd_weight(const void* dy, int dy_dtype, const float
   const int64_t npix = B * H * W;
   int64_t ppb = ceil_div64(npix, 1024);
   if (ppb < 16) ppb = 16;
-  if (dy_dtype == MFNET_BF16) hipLaunchKernelGGL(dwconv_bwd_weight_kernel<true>, dim3((unsigned)ceil_div64(npix, ppb)), dim3(256), 0, stream, dy, dy_dtype, x, dw, dbias, p, ppb, slots);
+  if ((k == 3 || k == 8) && npix >= 4096) {
+    // one workgroup per CU: the float atomics at the end (C * k * k per workgroup) are what the small maps pay for
+    ppb = (ceil_div64(npix, 256) + 15) / 16 * 16;
+    const dim3 gridw((unsigned)ceil_div64(npix, ppb));
+#define DW_PX(BF, KK) hipLaunchKernelGGL((dwconv_bwd_weight_px_kernel<BF, KK>), gridw, dim3(256), 0, stream, dy, x, dw, dbias, p, ppb, slots)
+    if (dy_dtype == MFNET_BF16) { if (k == 3) DW_PX(true, 3); else DW_PX(true, 8); }
+    else { if (k == 3) DW_PX(false, 3); else DW_PX(false, 8); }
+#undef DW_PX
+  } else if (dy_dtype == MFNET_BF16) hipLaunchKernelGGL(dwconv_bwd_weight_kernel<true>, dim3((unsigned)ceil_div64(npix, ppb)), dim3(256), 0, stream, dy, dy_dtype, x, dw, dbias, p, ppb, slots);
   else hipLaunchKernelGGL(dwconv_bwd_weight_kernel<false>, dim3((unsigned)ceil_div64(npix, ppb)), dim3(256), 0, stream, dy, dy_dtype, x, dw, dbias, p, ppb, slots);
   MF_LAUNCH_CHECK("dwconv_bwd_weight");
   return MFNET_OK;
