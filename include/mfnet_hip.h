@@ -196,6 +196,12 @@ int mfnet_gemm_tn_bf16(const void* dy, int64_t ldy, const void* x, int64_t ldx, 
  * (adapter.py:13-14 D_fc1 / D_fc2 of Img_ / DSM_ and MLPx_ / MLPy_Adapter). bias_part (nullable): [splits][n_groups][N]. */
 int mfnet_gemm_tn_bf16_grouped(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t M, int64_t N, int64_t K,
                                float* out, int64_t ldo, int splits, int n_groups, float* bias_part, hipStream_t stream);
+/* Several of the products above in ONE launch (they are independent of each other and of the backward chain: the weight
+ * gradients autograd would compute node by node for unetformer_mmsam.py:43-84 / adapter.py:17-25 only have to exist before the
+ * optimizer step, trainer.py:170-172). desc: 16 int64 per problem - dy, ldy, x, ldx, M (rows per group), N, K, out, ldo, splits,
+ * n_groups, bias_part (0: none), conv_H, conv_W, conv_C (0: a plain product; else x is a channels-last map and K = 9 * conv_C as
+ * in mfnet_gemm_tn_conv3x3), 0. Results and partial-tile layout per problem exactly as the one-problem entry points. */
+int mfnet_gemm_tn_batch(const int64_t* desc, int64_t n, hipStream_t stream);
 /* 3x3 / stride 1 / zero-pad 1 convolution of a channels-last bf16 map as an implicit GEMM (no column tensor): x [B*H*W, C]
  * (row stride ldx, C % 64 == 0), w [N, 9*C] with k = tap*C + c (tap = 3*ky + kx), out [B*H*W, N] bf16 or fp32: the 3x3 convs of
  * the decoder and the neck (unetformer_mmsam.py:43-60 ConvBNReLU / ConvBN / Conv with kernel_size=3, image_encoder.py:112-118).

@@ -19,6 +19,7 @@ gradient tensor back.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -40,6 +41,7 @@ class ParamBank:
         self._pending, self._notes = [], []
 
     def flush(self):
+        ops.tn_flush()              # the weight-gradient products collected during backward write the partial tiles gathered below
         if self._pending:
             ops.gather(self._pending, accumulate=True)
             for notify, p in self._notes:
@@ -56,6 +58,8 @@ class ParamBank:
 
     def __enter__(self):
         ParamBank.active = self
+        # deferred delivery: nothing reads a weight gradient before flush(), so the products that compute them are collected too
+        ops.TN_QUEUE = [] if (self.defer and os.environ.get("MFNET_TN_BATCH", "1") != "0") else None      # (=0: the A/B switch)
         self.refresh()
         return self
 
@@ -64,6 +68,7 @@ class ParamBank:
             self.flush()
         else:
             self._pending, self._notes = [], []
+        ops.TN_QUEUE = None
         ParamBank.active = None
         ops._twin[0] = None
         return False
@@ -168,6 +173,10 @@ def deliver(params: Sequence[torch.Tensor], grads: Sequence) -> tuple:
     """-> the gradient tuple to return to autograd for `params`. grads[i] is None, a tensor view shaped like
     params[i] (any strides), or a list of (row_slice, tensor) pieces that tile params[i] along dim 0."""
     out, pairs, notes = [], [], []
+    if ops.TN_QUEUE:
+        bank = ParamBank.active
+        if bank is None or not bank.defer or any(g is not None and getattr(p, "_mfnet_sink", None) is None for p, g in zip(params, grads)):
+            ops.tn_flush()          # a gradient leaves as a tensor, or is added right now: the collected products must have run
     for p, g in zip(params, grads):
         sink = getattr(p, "_mfnet_sink", None)
         if g is None:

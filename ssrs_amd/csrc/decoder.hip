@@ -1335,14 +1335,18 @@ extern "C" int mfnet_upfuse_fwd(const float* x, const void* skip, int skip_dtype
   MF_LAUNCH_CHECK("upfuse_fwd");
   return MFNET_OK;
 }
+__global__ void zero_f32_kernel(float* __restrict__ p, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0.f;
+}
 // df [B,H,W,C] fp32 -> dx [B,H/2,W/2,C] fp32, dskip (skip's row order), dw[2] += gradient of the fusion weights.
 // sums: scratch of 64 floats (32 slots x 2) owned by the caller (zeroed here).
 extern "C" int mfnet_upfuse_bwd(const float* df, const float* x, const void* skip, int skip_dtype, int perm, const float* w, float eps,
                                 float* dx, void* dskip, int dskip_dtype, float* dw, float* sums, int64_t B, int64_t H, int64_t W, int64_t C,
                                 hipStream_t stream) {
   MF_CHECK_ARG(df && x && skip && w && dx && dskip && dw && sums && C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && perm >= 0 && perm <= 2, "upfuse_bwd: bad args");
-  hipError_t e = hipMemsetAsync(sums, 0, 2 * UPFUSE_SLOTS * sizeof(float), stream);
-  if (e != hipSuccess) { mfnet_set_error("upfuse_bwd: memset: %s", hipGetErrorString(e)); return MFNET_ERR_HIP; }
+  // (a kernel, not hipMemsetAsync: as a memset NODE of a captured graph the clear was seen to lose its order against the kernels
+  // around it on the first replay after an idle second - garbage fusion-weight gradients)
+  hipLaunchKernelGGL(zero_f32_kernel, dim3(1), dim3(64), 0, stream, sums, 2 * UPFUSE_SLOTS);
   hipLaunchKernelGGL(upfuse_bwd_skip_kernel, dim3(grid_for(B * H * W * C / 4, 1024)), dim3(256), 0, stream, df, x, skip, skip_dtype, perm, w, eps, dskip,
                      dskip_dtype, sums, (int)B, (int)H, (int)W, (int)(C / 4));
   hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(B * (H / 2) * (W / 2) * C / 4)), dim3(256), 0, stream, df, w, eps, dx, (int)B, (int)(H / 2), (int)(W / 2),

@@ -337,21 +337,22 @@ extern "C" int mfnet_skinny_tn(const void* Y, int64_t ldy, const float* U, int64
 // CONV: X is a channels-last map [B*cH*cW, cC] and the k index runs over (tap, channel) of its 3x3 / pad 1 neighbourhood
 // (k = tap*cC + c): the weight gradient of a 3x3 convolution without the im2col tensor - the X rows of a k block are the map
 // rows of the pixels shifted by the block's tap, zero where that leaves the image.
+// (bx, by, bz) of nz: the workgroup's place in the problem's (k tiles, n tiles, splits * groups) grid - blockIdx of the
+// one-problem kernel, a slice of a 1-D grid in the batch kernel. lds_raw: 40 KB.
 template <bool CONV>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ DY, int64_t ldy, const bf16_t* __restrict__ X, int64_t ldx,
-                                                      int64_t M, int N, int K, int64_t rows_per_split, float* __restrict__ out, int64_t ldo,
-                                                      int splits, float* __restrict__ bias_part, int cH, int cW, int cC) {
+__device__ __forceinline__ void tn_body(unsigned char* lds_raw, const bf16_t* __restrict__ DY, int64_t ldy, const bf16_t* __restrict__ X, int64_t ldx,
+                                        int64_t M, int N, int K, int64_t rows_per_split, float* __restrict__ out, int64_t ldo,
+                                        int splits, float* __restrict__ bias_part, int cH, int cW, int cC, int bx, int by, int bz, int nz) {
   // staging: [wave][dy | x image][32 rows x 128 B]; after the row loop the same bytes carry the 4 -> 1 reduction of the waves'
   // accumulators (two 20-KB slots: 16 weight tiles + the bias tile of one wave)
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * 20 * 1024];
   unsigned char (*lds)[2][32 * 128] = reinterpret_cast<unsigned char (*)[2][32 * 128]>(lds_raw);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const int n0 = blockIdx.y * 64;
-  const int k0 = blockIdx.x * 64;
-  // blockIdx.z = split * n_groups + group: group g owns rows [g*M, (g+1)*M) of both operands; partial tile (split, group)
-  const int n_groups = gridDim.z / splits;
-  const int sp = blockIdx.z / n_groups, gz = blockIdx.z - sp * n_groups;
+  const int n0 = by * 64;
+  const int k0 = bx * 64;
+  // bz = split * n_groups + group: group g owns rows [g*M, (g+1)*M) of both operands; partial tile (split, group)
+  const int n_groups = nz / splits;
+  const int sp = bz / n_groups, gz = bz - sp * n_groups;
   DY += (int64_t)gz * M * ldy;
   X += (int64_t)gz * M * ldx;
   // the workgroup owns one 64 x 64 output tile over the split's rows; its four waves take a quarter of the rows each and their
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
   int64_t r_begin = s_begin + wave * rpw;
   if (r_begin > s_end) r_begin = s_end;
   const int64_t r_end = r_begin + rpw < s_end ? r_begin + rpw : s_end;
-  out += (int64_t)blockIdx.z * N * ldo;
+  out += (int64_t)bz * N * ldo;
   // bias gradient = column sums of dy over the same rows: the wave that owns k-tile 0 multiplies its dy fragments by a
   // fragment of ones as well (4 more MFMAs per step) and writes the partial row [N] of this (split, group)
   const bool want_b = bias_part != nullptr && k0 == 0;
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
   if (wave != 0) return;
   take(0);
   if (want_b && fr == 0) {
-    float* bo = bias_part + (int64_t)blockIdx.z * N;
+    float* bo = bias_part + (int64_t)bz * N;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -503,6 +504,39 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
     }
 }
 
+template <bool CONV>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ DY, int64_t ldy, const bf16_t* __restrict__ X, int64_t ldx,
+                                                      int64_t M, int N, int K, int64_t rows_per_split, float* __restrict__ out, int64_t ldo,
+                                                      int splits, float* __restrict__ bias_part, int cH, int cW, int cC) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * 20 * 1024];
+  tn_body<CONV>(lds_raw, DY, ldy, X, ldx, M, N, K, rows_per_split, out, ldo, splits, bias_part, cH, cW, cC, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z);
+}
+
+// Several independent weight-gradient products in ONE launch. The decoder / FPN / adapter weight gradients of a step are ~35
+// (MMAdapter: ~110) products of 1 to a few hundred workgroups each; launched one by one, the small ones are a serial chain of
+// 12-15 us latencies on a mostly idle chip (0.57 ms of the ViT-B MMLoRA step). None of them feeds the backward chain - they only
+// have to be done before the gradient delivery - so the host collects them and this kernel runs them side by side: workgroup id
+// -> problem by a scan of the start offsets (<= TN_BATCH problems, kernel arguments, no device table).
+#define TN_BATCH 24
+struct TnProb {
+  const bf16_t* DY; const bf16_t* X; float* out; float* bias_part;
+  int64_t ldy, ldx, M, rps, ldo;
+  int N, K, splits, nz, cH, cW, cC, gx, gy, wg_begin;
+};
+struct TnBatch { int n; TnProb p[TN_BATCH]; };
+__global__ __launch_bounds__(256) void gemm_tn_batch_kernel(const TnBatch b) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * 20 * 1024];
+  const int id = blockIdx.x;
+  int i = 0;
+  for (int j = 1; j < b.n; ++j)
+    if (id >= b.p[j].wg_begin) i = j;
+  const TnProb& q = b.p[i];
+  const int local = id - q.wg_begin;
+  const int bx = local % q.gx, t = local / q.gx, by = t % q.gy, bz = t / q.gy;
+  if (q.cC) tn_body<true>(lds_raw, q.DY, q.ldy, q.X, q.ldx, q.M, q.N, q.K, q.rps, q.out, q.ldo, q.splits, q.bias_part, q.cH, q.cW, q.cC, bx, by, bz, q.nz);
+  else tn_body<false>(lds_raw, q.DY, q.ldy, q.X, q.ldx, q.M, q.N, q.K, q.rps, q.out, q.ldo, q.splits, q.bias_part, 0, 0, 0, bx, by, bz, q.nz);
+}
+
 extern "C" int64_t mfnet_gemm_tn_splits(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 1;
   const int64_t tiles = ceil_div64(N, 64) * ceil_div64(K, 64);   // one 4-wave workgroup per tile and split
@@ -511,6 +545,53 @@ extern "C" int64_t mfnet_gemm_tn_splits(int64_t M, int64_t N, int64_t K) {
   if (s > smax) s = smax;
   if (s > 256) s = 256;
   return s < 1 ? 1 : s;
+}
+
+static int gemm_tn_check(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t M, int64_t N, int64_t K,
+                         float* out, int64_t ldo, int splits, int n_groups, int cC);
+// desc: 16 int64 per problem - dy, ldy, x, ldx, M (rows per group), N, K, out, ldo, splits, n_groups, bias_part (0: none),
+// conv_H, conv_W, conv_C (0: plain product; else x is a channels-last map and K = 9 * conv_C as in mfnet_gemm_tn_conv3x3), 0.
+extern "C" int mfnet_gemm_tn_batch(const int64_t* desc, int64_t n, hipStream_t stream) {
+  MF_CHECK_ARG(desc || n == 0, "gemm_tn_batch: null descriptor table");
+  MF_CHECK_ARG(n >= 0 && n <= 4096, "gemm_tn_batch: bad problem count");
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t* d = desc + 16 * i;
+    int rc = gemm_tn_check((const void*)d[0], d[1], (const void*)d[2], d[3], d[4], d[5], d[6], (float*)d[7], d[8], (int)d[9], (int)d[10], (int)d[14]);
+    if (rc) return rc;
+    MF_CHECK_ARG(d[14] == 0 || (d[12] > 0 && d[13] > 0 && d[14] % 64 == 0 && d[6] == 9 * d[14]), "gemm_tn_batch: bad conv geometry of problem %lld", (long long)i);
+  }
+  for (int64_t i0 = 0; i0 < n; i0 += TN_BATCH) {
+    TnBatch b;
+    b.n = (int)(n - i0 < TN_BATCH ? n - i0 : TN_BATCH);
+    int64_t total = 0;
+    for (int j = 0; j < b.n; ++j) {
+      const int64_t* d = desc + 16 * (i0 + j);
+      TnProb& q = b.p[j];
+      q.DY = (const bf16_t*)d[0]; q.ldy = d[1]; q.X = (const bf16_t*)d[2]; q.ldx = d[3]; q.M = d[4]; q.N = (int)d[5]; q.K = (int)d[6];
+      q.out = (float*)d[7]; q.ldo = d[8]; q.splits = (int)d[9]; q.nz = (int)(d[9] * d[10]); q.bias_part = (float*)d[11];
+      q.cH = (int)d[12]; q.cW = (int)d[13]; q.cC = (int)d[14];
+      q.rps = ceil_div64(ceil_div64(q.M, q.splits), 32) * 32;
+      q.gx = (int)ceil_div64(q.K, 64); q.gy = (int)ceil_div64(q.N, 64);
+      q.wg_begin = (int)total;
+      total += (int64_t)q.gx * q.gy * q.nz;
+      MF_CHECK_ARG(total < (1ll << 30), "gemm_tn_batch: too many workgroups");
+    }
+    for (int j = b.n; j < TN_BATCH; ++j) b.p[j] = b.p[0];
+    hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3((unsigned)total), dim3(256), 0, stream, b);
+    MF_LAUNCH_CHECK("gemm_tn_batch");
+  }
+  return MFNET_OK;
+}
+
+static int gemm_tn_check(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t M, int64_t N, int64_t K,
+                         float* out, int64_t ldo, int splits, int n_groups, int cC) {
+  MF_CHECK_ARG(dy && x && out, "gemm_tn: null pointer");
+  MF_CHECK_ARG(n_groups >= 1 && (int64_t)n_groups * splits <= 65535, "gemm_tn: bad group count");
+  MF_CHECK_ARG(M > 0 && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0, "gemm_tn: N=%lld and K=%lld must be multiples of 8", (long long)N, (long long)K);
+  MF_CHECK_ARG(ldy % 8 == 0 && ldx % 8 == 0 && ldy >= N && ldx >= (cC ? cC : K) && ldo >= K, "gemm_tn: bad leading dimensions");
+  MF_CHECK_ARG(((uintptr_t)dy | (uintptr_t)x) % 16 == 0, "gemm_tn: operands must be 16-byte aligned");
+  MF_CHECK_ARG(splits >= 1 && splits <= 65535 && N < (1ll << 31) && K < (1ll << 31), "gemm_tn: bad splits / shape");
+  return MFNET_OK;
 }
 
 static int gemm_tn_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t M, int64_t N, int64_t K,

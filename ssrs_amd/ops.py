@@ -8,6 +8,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 
 from . import _lib
@@ -283,6 +285,8 @@ class SplitSum:
         return SplitSum(self.part.transpose(1, 2), self.scale)
 
     def materialize(self):
+        if TN_QUEUE:
+            tn_flush()              # the partial tiles may belong to a product that is still collected
         out = torch.empty(tuple(self.shape), dtype=torch.float32, device=self.part.device)
         gather([(out, self)])
         return out
@@ -415,8 +419,12 @@ def conv3x3_wgrad(dy, x, G, H, W, want_bias=False):
     splits = int(_lib.lib().mfnet_gemm_tn_splits(M, N, K))
     part = torch.empty((splits, N, K), dtype=torch.float32, device=dy.device)
     bpart = torch.empty((splits, N), dtype=torch.float32, device=dy.device) if want_bias else None
-    call("mfnet_gemm_tn_conv3x3", dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), G, H, W, C, N, part.data_ptr(), K, splits,
-         bpart.data_ptr() if want_bias else None, _stream(dy))
+    if TN_QUEUE is not None:
+        _tn_enqueue((dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), M, N, K, part.data_ptr(), K, splits, 1,
+                     bpart.data_ptr() if want_bias else 0, H, W, C, 0), (dy, x, part, bpart))
+    else:
+        call("mfnet_gemm_tn_conv3x3", dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), G, H, W, C, N, part.data_ptr(), K, splits,
+             bpart.data_ptr() if want_bias else None, _stream(dy))
     dW = part[0] if splits == 1 else SplitSum(part)
     return (dW, SplitSum(bpart)) if want_bias else dW
 
@@ -629,6 +637,31 @@ def transpose_pad(x, mult=64):
     return y
 
 
+# Weight-gradient products whose result is only handed to the gradient delivery (lazy SplitSums) need not run where the
+# backward pass meets them: while a list is installed here (bank.ParamBank with deferred delivery does that) they are collected
+# - operands kept alive by the entries - and tn_flush() runs them all in one mfnet_gemm_tn_batch launch before the delivery's
+# gather reads their partial tiles. None: every product is launched on the spot.
+TN_QUEUE = None
+
+
+def _tn_enqueue(desc, keep):
+    TN_QUEUE.append((desc, keep))
+
+
+def tn_flush():
+    """launch the collected weight-gradient products (longest row ranges first: the long ones start early, the small ones fill
+    the gaps); the queue stays installed"""
+    q = TN_QUEUE
+    if not q:
+        return
+    import ctypes
+    entries = sorted(q, key=lambda e: -(e[0][4] // max(1, e[0][9])))          # rows per split
+    del q[:]
+    flat = [v for d, _ in entries for v in d]
+    arr = (ctypes.c_int64 * len(flat))(*flat)
+    call("mfnet_gemm_tn_batch", ctypes.cast(arr, ctypes.c_void_p), len(entries), _stream(entries[0][1][0]))
+
+
 def gemm_tn_grouped(dy, x, n_groups, want_bias=False):
     """n_groups independent dW_g[n,k] = sum over the rows of group g (M / n_groups consecutive rows each) of dy[m,n] x[m,k]
     in one launch -> SplitSum of shape [G, N, K] (index it per group and hand the pieces to deliver). want_bias: also the
@@ -642,8 +675,12 @@ def gemm_tn_grouped(dy, x, n_groups, want_bias=False):
     splits = int(_lib.lib().mfnet_gemm_tn_splits(Mg, N, K * n_groups))
     part = torch.empty((splits, n_groups, N, K), dtype=torch.float32, device=dy.device)
     bpart = torch.empty((splits, n_groups, N), dtype=torch.float32, device=dy.device) if want_bias else None
-    call("mfnet_gemm_tn_bf16_grouped", d2.data_ptr(), ldy, x2.data_ptr(), ldx, Mg, N, K, part.data_ptr(), K, splits, n_groups,
-         bpart.data_ptr() if want_bias else None, _stream(dy))
+    if TN_QUEUE is not None:
+        _tn_enqueue((d2.data_ptr(), ldy, x2.data_ptr(), ldx, Mg, N, K, part.data_ptr(), K, splits, n_groups,
+                     bpart.data_ptr() if want_bias else 0, 0, 0, 0, 0), (d2, x2, part, bpart))
+    else:
+        call("mfnet_gemm_tn_bf16_grouped", d2.data_ptr(), ldy, x2.data_ptr(), ldx, Mg, N, K, part.data_ptr(), K, splits, n_groups,
+             bpart.data_ptr() if want_bias else None, _stream(dy))
     return (SplitSum(part), SplitSum(bpart)) if want_bias else SplitSum(part)
 
 
@@ -661,8 +698,12 @@ def gemm_tn(dy, x, lazy=False, want_bias=False):
     splits = int(_lib.lib().mfnet_gemm_tn_splits(M, N, K))
     part = torch.empty((splits, N, K), dtype=torch.float32, device=dy.device)
     bpart = torch.empty((splits, N), dtype=torch.float32, device=dy.device) if want_bias else None
-    call("mfnet_gemm_tn_bf16", d2.data_ptr(), ldy, x2.data_ptr(), ldx, M, N, K, part.data_ptr(), K, splits,
-         bpart.data_ptr() if want_bias else None, _stream(dy))
+    if TN_QUEUE is not None and lazy:
+        _tn_enqueue((d2.data_ptr(), ldy, x2.data_ptr(), ldx, M, N, K, part.data_ptr(), K, splits, 1,
+                     bpart.data_ptr() if want_bias else 0, 0, 0, 0, 0), (d2, x2, part, bpart))
+    else:
+        call("mfnet_gemm_tn_bf16", d2.data_ptr(), ldy, x2.data_ptr(), ldx, M, N, K, part.data_ptr(), K, splits,
+             bpart.data_ptr() if want_bias else None, _stream(dy))
     if splits == 1:
         dW = part[0]
     elif lazy:

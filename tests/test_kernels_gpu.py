@@ -763,3 +763,43 @@ def test_tile_minmax_norm(ops, n, h, w):
         if keep:
             ref[0] = x[0]
         assert torch.equal(y, ref)
+
+
+def test_gemm_tn_batch_equals_one_by_one(ops):
+    """mfnet_gemm_tn_batch (the step's weight-gradient products collected and launched side by side) against the one-problem
+    entry points: plain, grouped and 3x3-conv problems of very different sizes in one batch, more problems than one launch
+    holds (24) - bit-identical partial tiles and bias rows."""
+    from ssrs_amd import ops as O
+    probs = []
+    for i, (M, N, K) in enumerate([(65536, 64, 64), (1024, 64, 256), (4096, 256, 64), (16384, 1024, 256), (1000, 72, 40)] * 6):
+        probs.append(("plain", rnd(M, N, seed=100 + i).to(torch.bfloat16), rnd(M, K, seed=200 + i).to(torch.bfloat16), i % 2 == 0))
+    probs.append(("grouped", rnd(8192, 192, seed=7).to(torch.bfloat16), rnd(8192, 768, seed=8).to(torch.bfloat16), True))
+    probs.append(("conv", rnd(2 * 16 * 16, 64, seed=9).to(torch.bfloat16), rnd(2 * 16 * 16, 64, seed=10).to(torch.bfloat16), True))
+
+    def run():
+        outs = []
+        for kind, dy, x, wb in probs:
+            if kind == "plain":
+                r = O.gemm_tn(dy, x, lazy=True, want_bias=wb)
+            elif kind == "grouped":
+                r = O.gemm_tn_grouped(dy, x, 2, want_bias=wb)
+            else:
+                r = O.conv3x3_wgrad(dy, x, 2, 16, 16, want_bias=wb)
+            outs.append(r if isinstance(r, tuple) else (r,))
+        return outs
+    assert O.TN_QUEUE is None
+    ref = run()
+    O.TN_QUEUE = []
+    try:
+        got = run()
+        assert len(O.TN_QUEUE) == len(probs)
+        O.tn_flush()
+        assert O.TN_QUEUE == []
+    finally:
+        O.TN_QUEUE = None
+    torch.cuda.synchronize()
+    for a, b in zip(ref, got):
+        for u, v in zip(a, b):
+            pu = u.part if isinstance(u, O.SplitSum) else u
+            pv = v.part if isinstance(v, O.SplitSum) else v
+            assert torch.equal(pu, pv)
