@@ -142,6 +142,10 @@ int64_t mfnet_lora_side_splits(int64_t Mg, int64_t C);
 int mfnet_lora_side(const void* Y, int64_t ldy, int64_t Mg, int64_t C, int n_groups, const float* U, int64_t ldu, int R,
                     float* dv_part, const float* Vt, int64_t ldvt, int64_t vt_group_stride, int RP, float* p_part,
                     hipStream_t stream);
+/* Several column products dV = Y^T . U of mfnet_lora_side (no Vt / P) in one launch - the dA = x^T . da products of the LoRA
+ * layers' backward (loralib/layers.py:149-165 differentiated w.r.t. lora_A), which feed nothing but the optimizer step. desc: 8
+ * int64 per problem - Y, ldy, Mg, C, n_groups, U, ldu, dv_part; one R (4 or 8) for all. Results per problem as mfnet_lora_side. */
+int mfnet_lora_side_batch(const int64_t* desc, int64_t n, int R, hipStream_t stream);
 
 /* ---- fused attention of the SAM blocks (lora_block.py:169-196 / adapter_fusionblock.py:176-198 with
  * add_decomposed_rel_pos :281-317, window_partition / window_unpartition :199-245).

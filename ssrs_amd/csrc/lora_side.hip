@@ -13,20 +13,21 @@
 // row splits (summed by the gradient delivery, like every other split weight gradient).
 #include "common.h"
 
+// (bx, by, bz) of (strips, ny splits, groups): the workgroup's place in the problem's grid - blockIdx of the one-problem kernel, a
+// slice of a 1-D grid in the batch kernel. lds: [wave][slab] images, 64 KB.
 template <int R, bool WANT_DV, bool WANT_P>
-__global__ __launch_bounds__(256, 2) void lora_side_kernel(const bf16_t* __restrict__ Y, int64_t ldy, const float* __restrict__ U, int64_t ldu,
-                                                           const float* __restrict__ Vt, int64_t ldvt, int64_t vt_group_stride, int RP,
-                                                           int64_t Mg, int C, int rpw, float* __restrict__ dv_part, float* __restrict__ p_part,
-                                                           int64_t Mtot) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[4][4][32 * 128];      // [wave][slab]: 64 KB
+__device__ __forceinline__ void lora_side_body(unsigned char (*lds)[4][32 * 128], const bf16_t* __restrict__ Y, int64_t ldy,
+                                               const float* __restrict__ U, int64_t ldu, const float* __restrict__ Vt, int64_t ldvt,
+                                               int64_t vt_group_stride, int RP, int64_t Mg, int C, int rpw, float* __restrict__ dv_part,
+                                               float* __restrict__ p_part, int64_t Mtot, int bx, int by, int bz, int ny) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const int g = blockIdx.z;
-  const int cw = blockIdx.x * 256;
+  const int g = bz;
+  const int cw = bx * 256;
   const int ns = (C - cw) >= 256 ? 4 : (C - cw) / 64;                              // 64-column slabs of this strip (wave-uniform)
   Y += (int64_t)g * Mg * ldy;
   if (WANT_DV) U += (int64_t)g * Mg * ldu;
-  const int64_t r_begin = ((int64_t)blockIdx.y * 4 + wave) * rpw;
+  const int64_t r_begin = ((int64_t)by * 4 + wave) * rpw;
   int64_t r_end = r_begin + rpw;
   if (r_end > Mg) r_end = Mg;
 
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void lora_side_kernel(const bf16_t* __restr
       for (int mb = 0; mb < 2; ++mb) {
         const int64_t m = m0 + 16 * mb + fr;
         if (m < r_end)
-          *reinterpret_cast<float4*>(p_part + ((int64_t)blockIdx.x * Mtot + (int64_t)g * Mg + m) * 8 + 4 * fq) =
+          *reinterpret_cast<float4*>(p_part + ((int64_t)bx * Mtot + (int64_t)g * Mg + m) * 8 + 4 * fq) =
               make_float4(accp[mb][0], accp[mb][1], accp[mb][2], accp[mb][3]);
       }
     }
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void lora_side_kernel(const bf16_t* __restr
       for (int r = 0; r < 4; ++r) mine[((s * 4 + t) * 4 + r) * 64 + lane] = acc[s][t][r];
   __syncthreads();
   if (wave < ns && fr < R) {
-    float* out = dv_part + (((int64_t)g * gridDim.y + blockIdx.y) * C) * R;
+    float* out = dv_part + (((int64_t)g * ny + by) * C) * R;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -163,6 +164,34 @@ __global__ __launch_bounds__(256, 2) void lora_side_kernel(const bf16_t* __restr
         out[(int64_t)c * R + fr] = v;
       }
   }
+}
+
+template <int R, bool WANT_DV, bool WANT_P>
+__global__ __launch_bounds__(256, 2) void lora_side_kernel(const bf16_t* __restrict__ Y, int64_t ldy, const float* __restrict__ U, int64_t ldu,
+                                                           const float* __restrict__ Vt, int64_t ldvt, int64_t vt_group_stride, int RP,
+                                                           int64_t Mg, int C, int rpw, float* __restrict__ dv_part, float* __restrict__ p_part,
+                                                           int64_t Mtot) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4][4][32 * 128];      // [wave][slab]: 64 KB
+  lora_side_body<R, WANT_DV, WANT_P>(lds, Y, ldy, U, ldu, Vt, ldvt, vt_group_stride, RP, Mg, C, rpw, dv_part, p_part, Mtot,
+                                     blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y);
+}
+
+// Several column products dV = Y^T . U (no P) in one launch: the dA = x^T . da products of a step (one per LoRA layer, 36 in the
+// ViT-B step) feed nothing but the gradient delivery, so the host collects them like the weight-gradient GEMMs (mfnet_gemm_tn_batch).
+#define LS_BATCH 24
+struct LsProb { const bf16_t* Y; const float* U; float* dv_part; int64_t ldy, ldu, Mg; int C, rpw, gx, gy, wg_begin, pad_; };
+struct LsBatch { int n; LsProb p[LS_BATCH]; };
+template <int R>
+__global__ __launch_bounds__(256, 2) void lora_side_batch_kernel(const LsBatch b) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4][4][32 * 128];
+  const int id = blockIdx.x;
+  int i = 0;
+  for (int j = 1; j < b.n; ++j)
+    if (id >= b.p[j].wg_begin) i = j;
+  const LsProb& q = b.p[i];
+  const int local = id - q.wg_begin;
+  const int bx = local % q.gx, t = local / q.gx, by = t % q.gy, bz = t / q.gy;
+  lora_side_body<R, true, false>(lds, q.Y, q.ldy, q.U, q.ldu, nullptr, 0, 0, 0, q.Mg, q.C, q.rpw, q.dv_part, nullptr, 0, bx, by, bz, q.gy);
 }
 
 static void lora_side_geometry(int64_t Mg, int64_t C, int64_t* strips, int64_t* splits, int* rpw) {
@@ -200,5 +229,38 @@ extern "C" int mfnet_lora_side(const void* Y, int64_t ldy, int64_t Mg, int64_t C
   else LS_LAUNCH(8, false, true);
 #undef LS_LAUNCH
   MF_LAUNCH_CHECK("lora_side");
+  return MFNET_OK;
+}
+
+// desc: 8 int64 per problem - Y, ldy, Mg (rows per group), C, n_groups, U, ldu, dv_part; all with the same R (4 or 8). Per problem
+// exactly mfnet_lora_side(Y, ldy, Mg, C, n_groups, U, ldu, R, dv_part, NULL, ...).
+extern "C" int mfnet_lora_side_batch(const int64_t* desc, int64_t n, int R, hipStream_t stream) {
+  MF_CHECK_ARG(desc || n == 0, "lora_side_batch: null descriptor table");
+  MF_CHECK_ARG(n >= 0 && n <= 4096 && (R == 4 || R == 8), "lora_side_batch: bad problem count / R = %d", R);
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t* d = desc + 8 * i;
+    MF_CHECK_ARG(d[0] && d[5] && d[7] && d[3] > 0 && d[3] % 64 == 0 && d[1] % 8 == 0 && d[1] >= d[3] && d[0] % 16 == 0 && d[4] >= 1 && d[4] <= 64 && d[2] > 0 && d[6] >= R,
+                 "lora_side_batch: bad problem %lld", (long long)i);
+  }
+  for (int64_t i0 = 0; i0 < n; i0 += LS_BATCH) {
+    LsBatch b;
+    b.n = (int)(n - i0 < LS_BATCH ? n - i0 : LS_BATCH);
+    int64_t total = 0;
+    for (int j = 0; j < b.n; ++j) {
+      const int64_t* d = desc + 8 * (i0 + j);
+      LsProb& q = b.p[j];
+      int64_t strips, splits; int rpw;
+      lora_side_geometry(d[2], d[3], &strips, &splits, &rpw);
+      MF_CHECK_ARG(splits <= 65535, "lora_side_batch: too many row splits");
+      q.Y = (const bf16_t*)d[0]; q.ldy = d[1]; q.Mg = d[2]; q.C = (int)d[3]; q.U = (const float*)d[5]; q.ldu = d[6]; q.dv_part = (float*)d[7];
+      q.rpw = rpw; q.gx = (int)strips; q.gy = (int)splits; q.wg_begin = (int)total; q.pad_ = 0;
+      total += strips * splits * d[4];
+      MF_CHECK_ARG(total < (1ll << 30), "lora_side_batch: too many workgroups");
+    }
+    for (int j = b.n; j < LS_BATCH; ++j) b.p[j] = b.p[0];
+    if (R == 4) hipLaunchKernelGGL(lora_side_batch_kernel<4>, dim3((unsigned)total), dim3(256), 0, stream, b);
+    else hipLaunchKernelGGL(lora_side_batch_kernel<8>, dim3((unsigned)total), dim3(256), 0, stream, b);
+    MF_LAUNCH_CHECK("lora_side_batch");
+  }
   return MFNET_OK;
 }

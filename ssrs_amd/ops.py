@@ -473,8 +473,12 @@ def lora_side(y, U=None, Vt=None, n_groups=1, scale=1.0):
         vgs = Vt.stride(0) if Vt.dim() == 3 else 0
         assert Vt.dim() == 2 or Vt.shape[0] == n_groups
         pp = torch.empty(((C + 255) // 256, M, 8), dtype=torch.float32, device=y.device)
-    call("mfnet_lora_side", y2.data_ptr(), ldy, Mg, C, n_groups, _p(U), U.stride(0) if U is not None else 0, R, _p(dv),
-         _p(Vt), ldvt, vgs, RP, _p(pp), _stream(y))
+    if TN_QUEUE is not None and Vt is None and R in (4, 8):
+        # the column product alone (dA = x^T . da): nothing but the gradient delivery reads it - collected like the wgrad GEMMs
+        _tn_enqueue((y2.data_ptr(), ldy, Mg, C, n_groups, U.data_ptr(), U.stride(0), dv.data_ptr()), (y2, U, dv), kind=("ls", R))
+    else:
+        call("mfnet_lora_side", y2.data_ptr(), ldy, Mg, C, n_groups, _p(U), U.stride(0) if U is not None else 0, R, _p(dv),
+             _p(Vt), ldvt, vgs, RP, _p(pp), _stream(y))
     if dv is not None:
         dv = SplitSum(dv.transpose(0, 1), scale)               # [splits, G, C, R], summed (x scale) by the gradient delivery
         if n_groups == 1:
@@ -644,22 +648,30 @@ def transpose_pad(x, mult=64):
 TN_QUEUE = None
 
 
-def _tn_enqueue(desc, keep):
-    TN_QUEUE.append((desc, keep))
+def _tn_enqueue(desc, keep, kind="tn"):
+    TN_QUEUE.append((kind, desc, keep))
 
 
 def tn_flush():
-    """launch the collected weight-gradient products (longest row ranges first: the long ones start early, the small ones fill
-    the gaps); the queue stays installed"""
+    """launch the collected weight-gradient products - one mfnet_gemm_tn_batch (longest row ranges first: the long ones start
+    early, the small ones fill the gaps) and one mfnet_lora_side_batch per LoRA rank; the queue stays installed"""
     q = TN_QUEUE
     if not q:
         return
     import ctypes
-    entries = sorted(q, key=lambda e: -(e[0][4] // max(1, e[0][9])))          # rows per split
+    entries = list(q)
     del q[:]
-    flat = [v for d, _ in entries for v in d]
-    arr = (ctypes.c_int64 * len(flat))(*flat)
-    call("mfnet_gemm_tn_batch", ctypes.cast(arr, ctypes.c_void_p), len(entries), _stream(entries[0][1][0]))
+    tn = sorted((e for e in entries if e[0] == "tn"), key=lambda e: -(e[1][4] // max(1, e[1][9])))          # rows per split
+    if tn:
+        flat = [v for _, d, _ in tn for v in d]
+        arr = (ctypes.c_int64 * len(flat))(*flat)
+        call("mfnet_gemm_tn_batch", ctypes.cast(arr, ctypes.c_void_p), len(tn), _stream(tn[0][2][0]))
+    for R in (4, 8):
+        ls = [e for e in entries if e[0] == ("ls", R)]
+        if ls:
+            flat = [v for _, d, _ in ls for v in d]
+            arr = (ctypes.c_int64 * len(flat))(*flat)
+            call("mfnet_lora_side_batch", ctypes.cast(arr, ctypes.c_void_p), len(ls), R, _stream(ls[0][2][0]))
 
 
 def gemm_tn_grouped(dy, x, n_groups, want_bias=False):

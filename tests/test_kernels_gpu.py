@@ -803,3 +803,20 @@ def test_gemm_tn_batch_equals_one_by_one(ops):
             pu = u.part if isinstance(u, O.SplitSum) else u
             pv = v.part if isinstance(v, O.SplitSum) else v
             assert torch.equal(pu, pv)
+
+
+def test_lora_side_batch_equals_one_by_one(ops):
+    """mfnet_lora_side_batch (the dA = x^T . da products of a step, collected) against mfnet_lora_side, both ranks, bit-identical."""
+    from ssrs_amd import ops as O
+    probs = [(rnd(8192, C, seed=30 + i).to(torch.bfloat16), rnd(8192, R, seed=60 + i)) for i, (C, R) in enumerate([(768, 4), (3072, 4), (768, 8), (128, 8), (3072, 4)] * 6)]
+    ref = [O.lora_side(y, U=u, n_groups=2)[0].part.clone() for y, u in probs]
+    O.TN_QUEUE = []
+    try:
+        got = [O.lora_side(y, U=u, n_groups=2)[0] for y, u in probs]
+        assert len(O.TN_QUEUE) == len(probs)
+        O.tn_flush()
+    finally:
+        O.TN_QUEUE = None
+    torch.cuda.synchronize()
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b.part)
