@@ -296,7 +296,7 @@ int mfnet_colsum(const void* x, int x_dtype, float* sum, float* sumsq, int64_t G
  * slabs and tickets live in a file-scope device array of the library (4 MiB + 4 KiB per GPU the library runs on, held until
  * the process ends). Limits: mfnet_colreduce_workspace_floats(G, P, C) <= 1048576 floats and G <= 1024, else MFNET_ERR_ARG
  * (every BatchNorm / SE / FRH reduction of MFNet at 16 tiles per GPU fits). It calls no hipMalloc / hipFree; the tickets are
- * cleared by a hipMemsetAsync on `stream`. All calls on one GPU share that GPU's array: calls that overlap in time on one
+ * cleared by a one-workgroup kernel on `stream`. All calls on one GPU share that GPU's array: calls that overlap in time on one
  * GPU (different streams, different threads) race - serialise them on one stream. The first call on each device looks the
  * array's address up (hipGetSymbolAddress): make it outside any stream capture. */
 int mfnet_colsum_static(const void* x, int x_dtype, float* sum, float* sumsq, int64_t G, int64_t P, int64_t C, hipStream_t stream);

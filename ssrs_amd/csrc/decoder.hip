@@ -15,6 +15,12 @@
 //   up_final_* : bilinear x4 of the class maps into NCHW logits, and its adjoint
 //   maxpool2_*, se_*, frh_gate_* : fpn4, SqueezeAndExcitation / SEFusion, FRH pixel+channel attention
 #include "common.h"
+
+// small clears run as kernels, not hipMemsetAsync: as a memset NODE of a captured graph a clear was seen to lose its order against
+// the kernels around it on the first replay after an idle second
+__global__ void zero_f32_kernel(float* __restrict__ p, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0.f;
+}
 #include <mutex>
 #include <stdlib.h>
 #include <float.h>
@@ -304,7 +310,7 @@ extern "C" int mfnet_colsum(const void* x, int x_dtype, float* sum, float* sumsq
 // ---- mfnet_colsum for callers that cannot allocate (HIP graph capture, tight serving loops, harnesses that forbid
 // hipMalloc): the same kernels, with the partial slabs and the tickets in a file-scope device array instead of a
 // caller workspace. `scratch` is a host-side stand-in in host code, never a device address: its per-device address is
-// taken ONCE per device with hipGetSymbolAddress and only that pointer is handed to kernels / hipMemsetAsync.
+// taken ONCE per device with hipGetSymbolAddress and only that pointer is handed to kernels.
 #define COLSUM_STATIC_MAX_FLOATS (1 << 20)     /* 4 MiB of partial slabs: G * splits * 2 * C floats */
 #define COLSUM_STATIC_MAX_GROUPS 1024          /* tickets, one per group */
 #define COLSUM_STATIC_MAX_DEVICES 64
@@ -341,12 +347,8 @@ extern "C" int mfnet_colsum_static(const void* x, int x_dtype, float* sum, float
   }
   unsigned int* tickets = (unsigned int*)(ptr + COLSUM_STATIC_MAX_FLOATS);
   // the array keeps the last call's contents: the slabs are fully rewritten before they are read, the tickets must start at
-  // zero - cleared here by a memset node on the caller's stream (a whole number of 16-byte units from a 256-byte-aligned start)
-  const hipError_t e = hipMemsetAsync(tickets, 0, (size_t)((G + 3) / 4 * 4) * sizeof(unsigned int), stream);
-  if (e != hipSuccess) {
-    mfnet_set_error("colsum_static: clearing the tickets failed: %s", hipGetErrorString(e));
-    return MFNET_ERR_HIP;
-  }
+  // zero - cleared here by a one-workgroup kernel on the caller's stream
+  hipLaunchKernelGGL(zero_f32_kernel, dim3(1), dim3(256), 0, stream, (float*)tickets, (int)((G + 3) / 4 * 4));      // (0.f is all-zero bits)
   ColRedParams p = {};
   p.a = x; p.a_dt = x_dtype; p.out0 = sum; p.out1 = sumsq; p.P = P; p.C = (int)C; p.mode = 0;
   return launch_colreduce(p, G, ptr, tickets, stream, "colsum_static");
@@ -1334,9 +1336,6 @@ extern "C" int mfnet_upfuse_fwd(const float* x, const void* skip, int skip_dtype
                      (int)B, (int)H, (int)W, (int)(C / 4));
   MF_LAUNCH_CHECK("upfuse_fwd");
   return MFNET_OK;
-}
-__global__ void zero_f32_kernel(float* __restrict__ p, int n) {
-  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0.f;
 }
 // df [B,H,W,C] fp32 -> dx [B,H/2,W/2,C] fp32, dskip (skip's row order), dw[2] += gradient of the fusion weights.
 // sums: scratch of 64 floats (32 slots x 2) owned by the caller (zeroed here).
