@@ -145,7 +145,14 @@ def main():
             real_all_reduce(h, op=op, group=group)
             t.copy_(h)
             return _Done() if async_op else None
-        dist.all_reduce = staged_all_reduce
+        real_broadcast = dist.broadcast
+
+        def staged_broadcast(t, src=0, group=None, async_op=False):
+            h = t.detach().cpu()
+            real_broadcast(h, src=src, group=group)
+            t.copy_(h)
+            return _Done() if async_op else None
+        dist.all_reduce, dist.broadcast = staged_all_reduce, staged_broadcast
     elif rehearsal == "nccl1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
