@@ -355,6 +355,10 @@ int mfnet_dwconv_bwd_data(const void* dy, int dy_dtype, const float* w, float* d
                           int64_t k, int ext, hipStream_t stream);
 int mfnet_dwconv_bwd_weight(const void* dy, int dy_dtype, const float* x, float* dw, float* dbias, int64_t B, int64_t H,
                             int64_t W, int64_t C, int64_t k, int ext, int slots, hipStream_t stream);
+/* Several depthwise weight gradients in one launch (independent of the backward chain, collected by the host like
+ * mfnet_gemm_tn_batch; what autograd computes node by node for the depthwise convs of unetformer_mmsam.py:52-84,117-131).
+ * desc: 12 int64 per problem - dy, dy_dtype, x, dw, dbias (0: none), B, H, W, C, k, ext, slots. */
+int mfnet_dwconv_bwd_weight_batch(const int64_t* desc, int64_t n, hipStream_t stream);
 
 /* GlobalLocalAttention's window attention (:169-186): qkv [B*H*W, 3*heads*8] bf16 in the 1x1 qkv conv's
  * channel order (which, head, d); 8x8 windows (H, W multiples of 8), softmax(q.k*scale +

@@ -74,6 +74,7 @@ _SIGS = {
     "mfnet_gemm_tn_bf16_grouped": [P, I64, P, I64, I64, I64, I64, P, I64, I, I, P, P],
     "mfnet_gemm_tn_batch": [P, I64, P],
     "mfnet_lora_side_batch": [P, I64, I, P],
+    "mfnet_dwconv_bwd_weight_batch": [P, I64, P],
     # ---- FPN / SE-fusion / UNetFormer decoder (csrc/decoder.hip)
     "mfnet_colsum": [P, I, P, P, I64, I64, I64, P, P, P],
     "mfnet_colsum_static": [P, I, P, P, I64, I64, I64, P],

@@ -701,13 +701,12 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const void* __rest
 #define DW_PU 4
 template <bool DY_BF16>      // the gradient's dtype is a template argument: a runtime switch around each load put a branch and a
                              // full memory wait between the loads of one iteration
-__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const void* __restrict__ dy, int dy_dt, const float* __restrict__ x,
-                                                                float* __restrict__ dw, float* __restrict__ dbias, const DwParams p,
-                                                                int64_t pix_per_block, int slots) {
+__device__ __forceinline__ void dw_tap_body(const void* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
+                                            float* __restrict__ dbias, const DwParams& p, int64_t pix_per_block, int slots, int bid) {
   const int C4 = p.C >> 2, kk = p.k * p.k;
   const int cg = threadIdx.x % C4, slot = threadIdx.x / C4, nslot = 256 / C4;
   const int64_t npix = (int64_t)p.B * p.H * p.W;
-  const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+  const int64_t p0 = (int64_t)bid * pix_per_block;
   int64_t p1 = p0 + pix_per_block;
   if (p1 > npix) p1 = npix;
   for (int tap = slot; tap < kk; tap += nslot) {
@@ -745,7 +744,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const void* __re
     }
     // same-address float atomics cost ~140 ns each on this chip: the workgroups spread over `slots` copies of dw / dbias
     // that the caller sums (512 workgroups on one copy: 70 of the kernel's 110 us)
-    const int sl = blockIdx.x % slots;
+    const int sl = bid % slots;
     float* o = dw + ((int64_t)sl * p.C + 4 * cg) * kk + tap;
     atomicAdd(o, acc.x); atomicAdd(o + kk, acc.y); atomicAdd(o + 2 * kk, acc.z); atomicAdd(o + 3 * kk, acc.w);
     if (dbias && tap == 0) {
@@ -754,22 +753,27 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const void* __re
     }
   }
 }
+template <bool DY_BF16>
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const void* __restrict__ dy, int dy_dt, const float* __restrict__ x,
+                                                                float* __restrict__ dw, float* __restrict__ dbias, const DwParams p,
+                                                                int64_t pix_per_block, int slots) {
+  dw_tap_body<DY_BF16>(dy, x, dw, dbias, p, pix_per_block, slots, blockIdx.x);
+}
 // K = 3 / 8: thread = (pixel slot, channel group) instead of (tap slot, channel group). Above, every tap slot streams the whole
 // chunk of dy again (k*k reads of dy and of x per pixel: 0.5 GB through L2 for the 8x8 kernel on the 32x32 maps, 59 us); here a
 // thread reads dy of a pixel once per pass of TG taps (one kernel row for K = 8, all nine taps for K = 3), holds TG float4
 // sums, and the 256 / C4 pixel slots of the workgroup meet in LDS before the (unchanged number of) atomics.
 template <bool DY_BF16, int K>
-__global__ __launch_bounds__(256) void dwconv_bwd_weight_px_kernel(const void* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
-                                                                   float* __restrict__ dbias, const DwParams p, int64_t pix_per_block, int slots) {
-  constexpr int TG = K == 3 ? 9 : K, NPASS = K * K / TG;
-  __shared__ float4 red[(TG + 1) * 256];                    // [tap of the pass | bias][pixel slot][channel group]
+__device__ __forceinline__ void dw_px_body(float4* red, const void* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
+                                           float* __restrict__ dbias, const DwParams& p, int64_t pix_per_block, int slots, int bid) {
+  constexpr int TG = K == 3 ? 9 : K, NPASS = K * K / TG;      // red: [tap of the pass | bias][pixel slot][channel group], (TG + 1) * 256 float4
   const int C4 = p.C >> 2, kk = K * K;
   const int cg = threadIdx.x % C4, ps = threadIdx.x / C4, nps = 256 / C4;
   const int64_t npix = (int64_t)p.B * p.H * p.W;
-  const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+  const int64_t p0 = (int64_t)bid * pix_per_block;
   int64_t p1 = p0 + pix_per_block;
   if (p1 > npix) p1 = npix;
-  const int sl = blockIdx.x % slots;
+  const int sl = bid % slots;
   for (int pass = 0; pass < NPASS; ++pass) {
     float4 acc[TG], bacc = F4ZERO;
 #pragma unroll
@@ -818,6 +822,29 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_px_kernel(const void* _
     }
   }
 }
+template <bool DY_BF16, int K>
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_px_kernel(const void* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
+                                                                   float* __restrict__ dbias, const DwParams p, int64_t pix_per_block, int slots) {
+  __shared__ float4 red[10 * 256];
+  dw_px_body<DY_BF16, K>(red, dy, x, dw, dbias, p, pix_per_block, slots, blockIdx.x);
+}
+// Several depthwise weight gradients in one launch (they feed nothing but the gradient delivery: collected by the host like the
+// weight-gradient GEMMs, mfnet_gemm_tn_batch). kind: 0 tap slots, 1 pixel slots k = 3, 2 pixel slots k = 8.
+#define DW_BATCH 16
+struct DwProb { const void* dy; const float* x; float* dw; float* dbias; DwParams p; int slots; int64_t ppb; int kind, bf16, wg_begin, pad_; };
+struct DwBatch { int n; DwProb q[DW_BATCH]; };
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_batch_kernel(const DwBatch b) {
+  __shared__ float4 red[10 * 256];
+  const int id = blockIdx.x;
+  int i = 0;
+  for (int j = 1; j < b.n; ++j)
+    if (id >= b.q[j].wg_begin) i = j;
+  const DwProb& q = b.q[i];
+  const int bid = id - q.wg_begin;
+  if (q.kind == 0) { if (q.bf16) dw_tap_body<true>(q.dy, q.x, q.dw, q.dbias, q.p, q.ppb, q.slots, bid); else dw_tap_body<false>(q.dy, q.x, q.dw, q.dbias, q.p, q.ppb, q.slots, bid); }
+  else if (q.kind == 1) { if (q.bf16) dw_px_body<true, 3>(red, q.dy, q.x, q.dw, q.dbias, q.p, q.ppb, q.slots, bid); else dw_px_body<false, 3>(red, q.dy, q.x, q.dw, q.dbias, q.p, q.ppb, q.slots, bid); }
+  else { if (q.bf16) dw_px_body<true, 8>(red, q.dy, q.x, q.dw, q.dbias, q.p, q.ppb, q.slots, bid); else dw_px_body<false, 8>(red, q.dy, q.x, q.dw, q.dbias, q.p, q.ppb, q.slots, bid); }
+}
 static int dw_check(DwParams* p, int64_t B, int64_t H, int64_t W, int64_t C, int64_t k, int ext, const char* who) {
   MF_CHECK_ARG(B > 0 && H > 1 && W > 1 && C > 0 && C % 4 == 0 && C <= 256 && 256 % (C / 4) == 0, "%s: bad geometry", who);
   MF_CHECK_ARG(k >= 1 && k <= 9 && (size_t)(k * k * C * 4) <= 64 * 1024, "%s: kernel size %lld unsupported", who, (long long)k);
@@ -857,6 +884,44 @@ extern "C" int mfnet_dwconv_bwd_data(const void* dy, int dy_dtype, const float* 
   return MFNET_OK;
 }
 // dw [slots][C, k*k] and dbias [slots][C] (optional) are ADDED into; the gradient is the sum over the slots.
+// kernel variant, pixels per workgroup and workgroup count of one depthwise weight gradient
+static void dw_weight_geometry(int64_t npix, int64_t k, int* kind, int64_t* ppb, int64_t* nwg) {
+  *ppb = ceil_div64(npix, 1024);
+  if (*ppb < 16) *ppb = 16;
+  *kind = 0;
+  if ((k == 3 || k == 8) && npix >= 4096) {
+    *ppb = (ceil_div64(npix, 256) + 15) / 16 * 16;      // one workgroup per CU (see the launcher below)
+    *kind = k == 3 ? 1 : 2;
+  }
+  *nwg = ceil_div64(npix, *ppb);
+}
+// desc: 12 int64 per problem - dy, dy_dtype, x, dw, dbias (0: none), B, H, W, C, k, ext, slots; per problem exactly
+// mfnet_dwconv_bwd_weight (dw / dbias are ADDED into).
+extern "C" int mfnet_dwconv_bwd_weight_batch(const int64_t* desc, int64_t n, hipStream_t stream) {
+  MF_CHECK_ARG(desc || n == 0, "dwconv_bwd_weight_batch: null descriptor table");
+  MF_CHECK_ARG(n >= 0 && n <= 1024, "dwconv_bwd_weight_batch: bad problem count");
+  for (int64_t i0 = 0; i0 < n; i0 += DW_BATCH) {
+    DwBatch b;
+    b.n = (int)(n - i0 < DW_BATCH ? n - i0 : DW_BATCH);
+    int64_t total = 0;
+    for (int j = 0; j < b.n; ++j) {
+      const int64_t* d = desc + 12 * (i0 + j);
+      DwProb& q = b.q[j];
+      MF_CHECK_ARG(d[0] && d[2] && d[3] && d[11] >= 1 && d[11] <= 64 && (d[1] == MFNET_BF16 || d[1] == MFNET_F32), "dwconv_bwd_weight_batch: bad problem %lld", (long long)(i0 + j));
+      int rc = dw_check(&q.p, d[5], d[6], d[7], d[8], d[9], (int)d[10], "dwconv_bwd_weight_batch");
+      if (rc) return rc;
+      q.dy = (const void*)d[0]; q.bf16 = d[1] == MFNET_BF16; q.x = (const float*)d[2]; q.dw = (float*)d[3]; q.dbias = (float*)d[4]; q.slots = (int)d[11];
+      int64_t nwg;
+      dw_weight_geometry(d[5] * d[6] * d[7], d[9], &q.kind, &q.ppb, &nwg);
+      q.wg_begin = (int)total; q.pad_ = 0;
+      total += nwg;
+    }
+    for (int j = b.n; j < DW_BATCH; ++j) b.q[j] = b.q[0];
+    hipLaunchKernelGGL(dwconv_bwd_weight_batch_kernel, dim3((unsigned)total), dim3(256), 0, stream, b);
+    MF_LAUNCH_CHECK("dwconv_bwd_weight_batch");
+  }
+  return MFNET_OK;
+}
 extern "C" int mfnet_dwconv_bwd_weight(const void* dy, int dy_dtype, const float* x, float* dw, float* dbias, int64_t B, int64_t H, int64_t W,
                                        int64_t C, int64_t k, int ext, int slots, hipStream_t stream) {
   MF_CHECK_ARG(dy && x && dw && slots >= 1 && slots <= 64, "dwconv_bwd_weight: null pointer / slots not in [1, 64]");

@@ -666,6 +666,11 @@ def tn_flush():
         flat = [v for _, d, _ in tn for v in d]
         arr = (ctypes.c_int64 * len(flat))(*flat)
         call("mfnet_gemm_tn_batch", ctypes.cast(arr, ctypes.c_void_p), len(tn), _stream(tn[0][2][0]))
+    dwq = [e for e in entries if e[0] == "dw"]
+    if dwq:
+        flat = [v for _, d, _ in dwq for v in d]
+        arr = (ctypes.c_int64 * len(flat))(*flat)
+        call("mfnet_dwconv_bwd_weight_batch", ctypes.cast(arr, ctypes.c_void_p), len(dwq), _stream(dwq[0][2][0]))
     for R in (4, 8):
         ls = [e for e in entries if e[0] == ("ls", R)]
         if ls:
@@ -913,8 +918,12 @@ def dwconv_bwd(dy, x, w, B, H, W, k, ext, want_bias=False):
     slots = 32                                           # copies of dw / db the workgroups spread their atomics over
     dw = zeros((slots,) + tuple(w.shape), x.device)
     db = zeros((slots, C), x.device) if want_bias else None
-    call("mfnet_dwconv_bwd_weight", dy.data_ptr(), _dt(dy), x.data_ptr(), dw.data_ptr(), _p(db), B, H, W, C, k, 1 if ext else 0, slots,
-         _stream(x))
+    if TN_QUEUE is not None:
+        _tn_enqueue((dy.data_ptr(), _dt(dy), x.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else 0, B, H, W, C, k, 1 if ext else 0, slots),
+                    (dy, x, dw, db), kind="dw")
+    else:
+        call("mfnet_dwconv_bwd_weight", dy.data_ptr(), _dt(dy), x.data_ptr(), dw.data_ptr(), _p(db), B, H, W, C, k, 1 if ext else 0, slots,
+             _stream(x))
     return dx, SplitSum(dw), (SplitSum(db) if want_bias else None)       # summed over the slots by the gradient delivery
 
 

@@ -820,3 +820,23 @@ def test_lora_side_batch_equals_one_by_one(ops):
     torch.cuda.synchronize()
     for a, b in zip(ref, got):
         assert torch.equal(a, b.part)
+
+
+def test_dwconv_bwd_weight_batch_matches_one_by_one(ops):
+    """mfnet_dwconv_bwd_weight_batch (collected depthwise weight gradients) against the one-problem entry point: all three kernel
+    variants in one batch. Float atomics: equal up to the summation order."""
+    from ssrs_amd import ops as O
+    cases = [(16, 8, 8, True), (16, 32, 8, True), (16, 64, 3, False), (2, 20, 3, True), (16, 16, 8, True)]
+    data = [(rnd(B * S * S, 64, seed=40 + i), rnd(B * S * S, 64, seed=50 + i), rnd(64, k * k, seed=70 + i), B, S, k, ext) for i, (B, S, k, ext) in enumerate(cases)]
+    ref = [O.dwconv_bwd(dy, x, w, B, S, S, k, ext, want_bias=True) for dy, x, w, B, S, k, ext in data]
+    ref = [(r[1].materialize(), r[2].materialize()) for r in ref]
+    O.TN_QUEUE = []
+    try:
+        got = [O.dwconv_bwd(dy, x, w, B, S, S, k, ext, want_bias=True) for dy, x, w, B, S, k, ext in data]
+        assert len(O.TN_QUEUE) == len(cases)
+        O.tn_flush()
+        got = [(r[1].materialize(), r[2].materialize()) for r in got]
+    finally:
+        O.TN_QUEUE = None
+    for (a, b), (c, d) in zip(ref, got):
+        assert rel_err(c, a) < 1e-5 and rel_err(d, b) < 1e-5
