@@ -323,6 +323,33 @@ def test_engine_checkpoint_round_trip(use_graph):
         e2.load_state_dict(bad)
 
 
+def test_graph_replay_after_an_idle_second_matches_eager():
+    """A replay that follows a pause must compute what an eager step computes. Background: a hipMemsetAsync inside the captured
+    step - a memset NODE - lost its order against its neighbours on the first replay after the GPU had idled (garbage
+    fusion-weight gradients); whether it shows depends on the graph pool's layout - test_engine_checkpoint_round_trip[True] run
+    after [False] is where it surfaced, this sequence alone did not trip it - so the step simply holds no memset node any more
+    and this test watches the symptom (loss trajectories of an eager and a replayed engine with idle seconds between steps)."""
+    import time
+    from ssrs_amd.trainer import TrainEngine
+    fill = detfill.fill_state_dict(_tiny_model("sam_lora").state_dict(), "idle/")
+    rgb, dsm, tgt = [t.cuda() for t in detfill.tiles("idle", 2, 256, 6)]
+    traj = {}
+    for use_graph in (False, True):
+        m = _tiny_model("sam_lora")
+        m.load_state_dict(fill)
+        m = m.cuda().train()
+        m.decoder.segmentation_head[1].p = 0.0
+        eng = TrainEngine(m, lr=0.01, momentum=0.9, weight_decay=5e-4, class_weight=torch.ones(6, device="cuda"), use_graph=use_graph)
+        losses = []
+        for step in range(6):
+            if step in (3, 5):
+                torch.cuda.synchronize()
+                time.sleep(1.0)
+            losses.append(TrainEngine.read_metrics(eng.step(rgb, dsm, tgt))["loss"])
+        traj[use_graph] = losses
+    assert np.allclose(traj[True], traj[False], rtol=2e-3, atol=0), traj
+
+
 def test_cpu_tensors_are_rejected_loudly():
     from ssrs_amd._lib import MfnetError
     m = _tiny_model("sam_lora")
