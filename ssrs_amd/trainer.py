@@ -106,6 +106,7 @@ class TrainEngine:
             raise ValueError("sync_bn exchanges statistics inside the step: use_graph=False")
         self.overlap = overlap and not self.use_graph        # autograd hooks do not run when a graph is replayed
         self._graphs = {}
+        self.keep_graph = False          # True: the captured hipGraph_t stays readable (graph_census.census(engine.captured_graph(...)))
         self._eager_warmup = 2
         named, n_head = trainable_tensors(model)
         if not named:
@@ -262,7 +263,7 @@ class TrainEngine:
                 return self.forward_backward(rgb, dsm, target)[0]
             srgb, sdsm, stgt = rgb.clone(), dsm.clone(), target.clone()
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
+            g = torch.cuda.CUDAGraph(keep_graph=True) if self.keep_graph else torch.cuda.CUDAGraph()
             # thread_local: RCCL's watchdog thread polls its events while this thread captures; under the default
             # (global) mode that poll is an illegal call during capture and takes the process down
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
@@ -278,6 +279,10 @@ class TrainEngine:
             stgt.copy_(target, non_blocking=True)
         g.replay()
         return acc
+
+    def captured_graphs(self):
+        """the torch.cuda.CUDAGraph objects captured so far, one per input shape (keep_graph=True makes them inspectable)."""
+        return [ent[0] for ent in self._graphs.values()]
 
     @staticmethod
     def read_metrics(acc: torch.Tensor) -> Dict[str, float]:
@@ -491,15 +496,24 @@ class Trainer:
         return float(miou)
 
     def save_checkpoint(self, epoch: int, miou: float) -> None:
+        """trainer.py:379-394. Holds NO collective: under data parallelism `train()` has already made the replicas
+        identical (`broadcast_state`) and the mIoU rank 0's, so every rank takes the same branch."""
         if miou > self.best_miou:
             self.best_miou = miou
-            self.engine.broadcast_state()          # rank 0's BatchNorm running statistics become everybody's
             if self.rank == 0:
                 import os
                 os.makedirs(self.output_dir, exist_ok=True)
                 self.model_wrapper.save_weights(f"{self.output_dir}{self.model_name}_epoch{epoch}_{miou:.4f}")
         elif self.rank == 0:
             print(f"   No improvement (best: {self.best_miou:.4f})")
+
+    def _rank0_value(self, value: float) -> float:
+        """rank 0's float on every rank (one 8-byte broadcast; nothing to do alone)."""
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return float(value)
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.engine.flat_p.device)
+        dist.broadcast(t, src=0)
+        return float(t.item())
 
     def train(self, epochs: Optional[int] = None, save_epoch: Optional[int] = None) -> None:
         epochs = self.epochs if epochs is None else epochs
@@ -512,4 +526,10 @@ class Trainer:
                 print(f"EPOCH {epoch:2d}/{epochs}  train {metrics['training_time']:.2f}s  total {time.time() - t0:.2f}s  "
                       f"avg loss {metrics['avg_loss']:.4f}  lr {self.engine.lr:.2e}")
             if epoch % save_epoch == 0:
-                self.save_checkpoint(epoch, self.validate(epoch))
+                # Data parallel: per-replica BatchNorm running statistics differ between ranks, so rank 0's state
+                # goes to every rank BEFORE the validation - the mIoU then describes the model that is saved, whichever rank
+                # evaluated which band of windows. The collectives are unconditional (same sequence on every rank), and the
+                # best-mIoU comparison runs on rank 0's value so no rank can take the other branch.
+                self.engine.broadcast_state()
+                miou = self._rank0_value(self.validate(epoch))
+                self.save_checkpoint(epoch, miou)

@@ -12,12 +12,12 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _tiny(train=False):
+def _tiny(train=False, mod="sam_lora"):
     import argparse
     import warnings
     from ssrs_amd import detfill
     from ssrs_amd.unetformer_mmsam import UNetFormer
-    args = argparse.Namespace(mod="sam_lora", mid_dim=None, image_size=1024, multimask_output=1)
+    args = argparse.Namespace(mod=mod, mid_dim=None, image_size=1024, multimask_output=1)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         m = UNetFormer(num_classes=6, encoder="vit_tiny_test", args=args, dropout=0.0 if train else 0.1)
@@ -46,7 +46,7 @@ def _stage_collectives():
     dist.all_reduce, dist.broadcast = all_reduce, broadcast
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mod):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         torch.cuda.set_device(0)
@@ -57,15 +57,17 @@ def _worker(rank, world, port, q):
         rgb, dsm, tgt = [t.cuda() for t in detfill.tiles("dp", 2, 256, 6)]
         w = torch.ones(6, device="cuda")
         # single-process gradients of the whole batch, plain autograd, no engine
-        ref_m = _tiny()
+        ref_m = _tiny(mod=mod)
         named, _ = trainable_tensors(ref_m)
+        token = "lora_" if mod == "sam_lora" else "Adapter"   # the PEFT family of this variant is what sits in bucket 1
+        assert any(token in n for n, _ in named) and not any(("Adapter" if token == "lora_" else "lora_") in n for n, _ in named)
         out = ref_m(rgb, dsm, mode="Train").contiguous()
         acc, _ = ops.ce_loss_fwd(out, tgt, w, -100)
         out.backward(ops.ce_loss_bwd(out, tgt, acc, w, -100, 1.0))
         ref = torch.cat([p.grad.reshape(-1) for _, p in named])
         worst = 0.0
         for overlap in (True, False):
-            m = _tiny()
+            m = _tiny(mod=mod)
             if rank == 1:                                   # replicas that start apart must be pulled together by the engine
                 with torch.no_grad():
                     m.decoder.segmentation_head[2][0].weight.add_(0.25)
@@ -89,10 +91,11 @@ def _worker(rank, world, port, q):
             dist.destroy_process_group()
 
 
-def test_two_rank_gradients_equal_single_process_gradients():
+@pytest.mark.parametrize("mod,port", [("sam_lora", 29631), ("sam_adpt", 29633)])      # BASELINE configs[2] is the MMAdapter variant
+def test_two_rank_gradients_equal_single_process_gradients(mod, port):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, 29631, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mod)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in range(2)]
@@ -108,7 +111,7 @@ def _bn_buffers(m):
     return torch.cat([b.detach().float().reshape(-1) for n, b in m.named_buffers() if n.endswith(("running_mean", "running_var"))])
 
 
-def _worker_sync_bn(rank, world, port, q):
+def _worker_sync_bn(rank, world, port, q, mod):
     """BatchNorm in TRAINING mode: with sync_bn the two ranks' one-tile batches must behave like the single-process two-tile
     batch (torch.nn.SyncBatchNorm's contract; SURVEY 8(e) strict 1-vs-N mode) - loss, averaged gradients, running statistics.
     Per-replica statistics (the default) are measured beside it: they must be far off, or the test proves nothing."""
@@ -121,7 +124,7 @@ def _worker_sync_bn(rank, world, port, q):
         from ssrs_amd.trainer import TrainEngine, trainable_tensors
         rgb, dsm, tgt = [t.cuda() for t in detfill.tiles("dpbn", 2, 256, 6)]
         w = torch.ones(6, device="cuda")
-        ref_m = _tiny(train=True)
+        ref_m = _tiny(train=True, mod=mod)
         named, _ = trainable_tensors(ref_m)
         out = ref_m(rgb, dsm, mode="Train").contiguous()
         acc, _ = ops.ce_loss_fwd(out, tgt, w, -100)
@@ -131,7 +134,7 @@ def _worker_sync_bn(rank, world, port, q):
         ref_buf = _bn_buffers(ref_m)
         res = {}
         for sync in (True, False):
-            m = _tiny(train=True)
+            m = _tiny(train=True, mod=mod)
             eng = TrainEngine(m, lr=0.01, momentum=0.9, weight_decay=5e-4, class_weight=w, overlap=False, sync_bn=sync)
             sl = slice(rank, rank + 1)
             eng.zero_grad()
@@ -152,10 +155,11 @@ def _worker_sync_bn(rank, world, port, q):
             dist.destroy_process_group()
 
 
-def test_sync_bn_two_ranks_equal_single_process_batch():
+@pytest.mark.parametrize("mod,port", [("sam_lora", 29641), ("sam_adpt", 29643)])
+def test_sync_bn_two_ranks_equal_single_process_batch(mod, port):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_sync_bn, args=(r, 2, 29641, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_sync_bn, args=(r, 2, port, q, mod)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in range(2)]

@@ -161,4 +161,4 @@ def test_1024_tile_fp32_and_bf16_paths_agree():
     e = rel_err(lo, hi)
     agree = float((lo.argmax(1) == hi.argmax(1)).float().mean())
     print(f"\n[vit_b 1024x1024] bf16 vs fp32 path: logits {e:.3e}, argmax agreement {100 * agree:.3f} %")
-    assert e < 2e-2 and agree > 0.98
+    assert e < 2e-2 and agree >= 0.99, (e, agree)          # measured 1.2e-2 / 99.35 % (1 M pixels of near-tied random-init logits)

@@ -364,3 +364,41 @@ def _share_rows_worker(rank, world, port, q):
 def test_owned_rows_are_gathered_not_all_reduced_gloo():
     for rank, ok in _run(_share_rows_worker, 2, 29614):
         assert ok, rank
+
+
+def _dp_validate_worker(rank, world, port, q):
+    """Advisor finding (round 2): validation must see rank 0's state on every rank, and the best-mIoU branch must not
+    depend on a rank-local value. The ranks' BatchNorm-like buffer diverges during the epoch and their validate_fn
+    returns different mIoUs straddling `best_miou`; every rank must validate with rank 0's buffer, agree on rank 0's
+    mIoU, and finish train() without a stray collective (a hang shows as the test's timeout)."""
+    from ssrs_amd import trainer as T
+    _init(rank, world, port)
+    torch.manual_seed(0)
+    m = _Toy()
+    m.register_buffer("running_stat", torch.zeros(3))
+
+    def step(self, data, dsm, target):
+        m.running_stat.fill_(10.0 + rank)                 # per-replica statistics drift apart
+        return torch.tensor([1.0, 1.0, 1.0, 1.0])
+    T.TrainEngine.step = step
+    seen = []
+
+    def validate_fn(mw):
+        seen.append(float(mw.model.running_stat[0]))
+        return 0.90 if rank == 0 else 0.50                # only rank 0's value beats best_miou = 0.82
+
+    mw = _StubWrapper(m)
+    tr = T.Trainer(mw, None, train_loader=list(_loader(2)), validate_fn=validate_fn, output_dir="/tmp/mfnet_dpval_%d/" % port)
+    tr.train(epochs=2, save_epoch=1)
+    probe = torch.ones(1)
+    dist.all_reduce(probe)                                # the ranks are still in step with each other
+    q.put((rank, (seen, tr.best_miou, len(mw.saved), float(probe))))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_dp_validation_uses_rank0_state_and_rank0_miou_gloo():
+    for rank, (seen, best, nsaved, probe) in _run(_dp_validate_worker, 2, 29615):
+        assert seen == [10.0, 10.0], (rank, seen)         # rank 0's buffer on every rank at validation time
+        assert best == 0.90 and probe == 2.0, (rank, best, probe)
+        assert nsaved == (1 if rank == 0 else 0), (rank, nsaved)   # first epoch improves, the second does not

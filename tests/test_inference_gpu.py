@@ -73,7 +73,9 @@ def test_sliding_predict_with_model_vs_oracle():
         ref_mask, ref = R.predict_sliding(lambda a, b: R.unetformer(sd, a.double(), b.double(), cfg), img.permute(1, 2, 0), dsm, 6, 64, 4, (256, 256))
     assert lo == 0 and scores.shape == (6, H, W)
     assert rel_err(scores.permute(1, 2, 0), ref) < 2e-2
-    assert (mask.cpu().numpy() == ref_mask.numpy()).mean() > 0.98
+    agree = float((mask.cpu().numpy() == ref_mask.numpy()).mean())
+    print(f"\n[sliding predict, tiny model] summed-logit argmax agreement with the oracle {100 * agree:.3f} %")
+    assert agree >= 0.994, agree
 
 
 def test_graph_replayed_forward_is_bit_identical_to_eager():

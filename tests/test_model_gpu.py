@@ -113,7 +113,7 @@ def _check_masks(out, g, tgt, ncls=6):
     pred = out.argmax(1).cpu().numpy()
     ref_mask = g["eval_argmax"]
     agree = (pred == ref_mask).mean()
-    assert agree >= 0.98, agree
+    assert agree >= 0.994, agree                    # measured 99.4-99.9 % on the random-init fixtures (the fp32 path: >= 99.9 %)
     ref = g["eval_logits_s4"]
     srt = np.sort(ref, axis=1)
     margin = srt[:, -1] - srt[:, -2]
@@ -244,7 +244,8 @@ def test_vitb_eval_logits_vs_reference():
 
 @pytest.mark.parametrize("mod,encoder,tile,batch", [("sam_adpt", "vit_b", 256, 2), ("sam_lora", "vit_b", 256, 2), ("sam_lora", "vit_l", 512, 1),
                                                     ("sam_lora", "vit_h", 256, 1), ("sam_adpt", "vit_h", 256, 1),
-                                                    ("sam_lora", "vit_l", 1024, 1)])     # BASELINE configs[4]: whole 1024x1024 tile, 64x64 token grid
+                                                    ("sam_lora", "vit_l", 1024, 1),      # BASELINE configs[4]: whole 1024x1024 tile, 64x64 token grid
+                                                    ("sam_lora", "vit_h", 1024, 1)])     # configs[4] names ViT-H too (build_sam.py:16-24): head dim 80, 32 blocks
 def test_full_size_train_steps_run_and_learn(mod, encoder, tile, batch):
     """SURVEY 8(d) configurations at their real widths (768 / 1024 / 1280 channels, head dim 80 for ViT-H, adapters, a
     32x32 token grid with 9 windows for ViT-L at 512 px) through the graph-captured engine: every kernel accepts its shapes, the loss is finite
@@ -348,6 +349,29 @@ def test_graph_replay_after_an_idle_second_matches_eager():
             losses.append(TrainEngine.read_metrics(eng.step(rgb, dsm, tgt))["loss"])
         traj[use_graph] = losses
     assert np.allclose(traj[True], traj[False], rtol=2e-3, atol=0), traj
+
+
+@pytest.mark.parametrize("mod", ["sam_lora", "sam_adpt"])
+def test_captured_step_holds_kernel_nodes_only(mod):
+    """The replayed train step must be a chain of KERNEL nodes: no memset / memcpy node (the node class that lost its order on
+    a replay after an idle second), no host node, one root, fan-in 1. Read from the captured hipGraph_t itself
+    (ssrs_amd/graph_census.py: hipGraphGetNodes / hipGraphNodeGetType / hipGraphNodeGetDependencies); the censuses of the tiny
+    and the ViT-B step are committed as profiles/r03_a_graph_census_*.json."""
+    from ssrs_amd.graph_census import census
+    from ssrs_amd.trainer import TrainEngine
+    m = _tiny_model(mod)
+    m.load_state_dict(detfill.fill_state_dict(m.state_dict(), "census/"))
+    m = m.cuda().train()
+    rgb, dsm, tgt = [t.cuda() for t in detfill.tiles("census", 2, 256, 6)]
+    eng = TrainEngine(m, lr=0.01, momentum=0.9, weight_decay=5e-4, class_weight=torch.ones(6, device="cuda"), use_graph=True)
+    eng.keep_graph = True
+    losses = [TrainEngine.read_metrics(eng.step(rgb, dsm, tgt))["loss"] for _ in range(5)]      # 2 eager, capture + replay, 2 replays
+    assert losses[-1] < losses[0]
+    (g,) = eng.captured_graphs()
+    c = census(g)
+    print(f"\n[captured step, tiny {mod}] {c['nodes']} nodes: {c['types']}, roots {c['roots']}, max fan-in {c['max_fan_in']}")
+    assert c["types"] == {"kernel": c["nodes"]} and c["nodes"] > 100, c["types"]
+    assert not c["non_kernel"] and c["roots"] == 1 and c["max_fan_in"] == 1, c
 
 
 def test_cpu_tensors_are_rejected_loudly():
