@@ -423,7 +423,9 @@ int mfnet_add3(const void* a, int a_dtype, const void* b, int b_dtype, const voi
  * std3 are HOST arrays). extract_tiles: coords[t] = (row, col, valid_h, valid_w) int32; tiles shorter than the
  * h x w window are filled with numpy 'reflect' padding (:726-737). tile_minmax_norm: per-tile DSM min-max in
  * place; a flat tile (max == min) becomes 0 (:547-555) or, with keep_flat, stays as it is (multiscale_dataset.py:206). tile_prob_accumulate: sum[row+y, col+x] += softmax(logits[t])[cls],
- * cnt += 1 over each tile's valid extent (:562-566). blend_finish: prob = sum/cnt, mask = prob >= threshold (:582).
+ * cnt += 1 over each tile's valid extent (:562-566); both accumulators are int64 - sum in fixed point (probability * 2^40), so the
+ * atomic adds commute and the blend is bit-identical for any window order / rank count. blend_finish: prob = sum/2^40/cnt,
+ * mask = prob >= threshold (:582).
  * normalize_raster: BuildingInference._normalize_image (:444-496) on a whole [C,H,W] raster; in_kind 0 uint8 (/255),
  * 1 uint16 (/65535), 2 fp32 (clip((v - sub)/div, 0, 1) with the host-computed 2nd / 98th percentiles when clip != 0);
  * is_rgb == 0 keeps raw values (the DEM, :485-488); ImageNet mean / std (HOST arrays) only when C == 3; pixels where any
@@ -444,14 +446,14 @@ int mfnet_tile_minmax_norm(float* tiles, int64_t n, int64_t per_tile, int keep_f
 int mfnet_prepare_tiles(const unsigned char* rgb, const float* dsm, const int64_t* labels, const int* codes,
                         float* rgb_out, float* dsm_out, int64_t* labels_out, int64_t n, int64_t S,
                         const float* mean3, const float* std3, hipStream_t stream);
-int mfnet_tile_prob_accumulate(float* sum, float* cnt, const float* logits, const int* coords, int64_t n, int64_t C, int64_t H,
+int mfnet_tile_prob_accumulate(int64_t* sum, int64_t* cnt, const float* logits, const int* coords, int64_t n, int64_t C, int64_t H,
                                int64_t W, int64_t h, int64_t w, int64_t cls, hipStream_t stream);
 int mfnet_normalize_raster(const void* in, int in_kind, int64_t C, int64_t H, int64_t W, int is_rgb, int clip, float sub,
                            float div, const float* mean3, const float* std3, int has_nodata, double nodata_value, float* out,
                            unsigned char* nodata_mask, hipStream_t stream);
 int mfnet_tile_prob_mask(const float* logits, const int* coords, float* prob, unsigned char* mask, int64_t n, int64_t C,
                          int64_t h, int64_t w, int64_t cls, float threshold, hipStream_t stream);
-int mfnet_blend_finish(const float* sum, const float* cnt, float* prob, unsigned char* mask, float threshold, int64_t n,
+int mfnet_blend_finish(const int64_t* sum, const int64_t* cnt, float* prob, unsigned char* mask, float threshold, int64_t n,
                        hipStream_t stream);
 /* cm[gt*n + pred] += 1 for pixels with 0 <= gt < n: the confusion matrix behind utils2.metrics (utils2.py:168-216),
  * pred uint8, gt int64, cm int64 [n,n] (zero first), n <= 32. */

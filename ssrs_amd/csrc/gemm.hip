@@ -169,22 +169,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) bias4[ni] = *reinterpret_cast<const float4*>(biasg + nbc + 4 * ni);
   }
-  // Low-rank update = extra MFMA k-steps whose 32 k-slots hold the rank index up to three times:
-  // slots [0,Rp) U_hi.V_hi, [Rp,2Rp) U_lo.V_hi, [2Rp,3Rp) U_hi.V_lo (hi = bf16(x), lo = bf16(x - hi); Rp = 8
-  // for R <= 8 -> one k-step, else 16 -> two), so the fp32 U (x lr_scale) and V keep ~16 mantissa bits
-  // although the product runs on the bf16 matrix cores. Every lane needs the same 8 floats for each slot
-  // group; the modality group is uniform per workgroup (the host splits launches that would straddle).
-  const int R = p.R, Rp = R <= 8 ? 8 : 16;
-  const int lk0 = Rp == 8 ? 0 : 8 * (fq & 1);
+  // Low-rank update = one extra MFMA k-step per 8 ranks whose 32 k-slots hold the rank index three times:
+  // slots [0,8) U_hi.V_hi, [8,16) U_lo.V_hi, [16,24) U_hi.V_lo (hi = bf16(x), lo = bf16(x - hi)), so the fp32 U (x lr_scale)
+  // and V keep ~16 mantissa bits although the product runs on the bf16 matrix cores; lane quarter fq owns product fq of
+  // the pass's ranks. R <= 8 (the default LoRA rank 4: stacked factors of 8 columns) is one pass whose factor rows are
+  // requested here, ahead of the main loop; LoRA ranks up to 16 (R <= 32) take up to four, the later ones fetched in the
+  // epilogue. The modality group is uniform per workgroup (the host splits launches that would straddle).
+  const int R = p.R;
   float4 uraw[4][2], vraw[4][2];
-  if (LORA) {
+  const float* vg = LORA ? p.V + (int64_t)grp * p.v_group_stride : nullptr;
+  auto load_factors = [&](int lk0) {
     // unconditional loads (a masked-off second half re-reads the first): no branch, no wait between them
     const int lk1 = lk0 + 4 < R ? lk0 + 4 : lk0;
     auto load_raw = [&](float4 (&dst)[2], const float* src) {
       dst[0] = *reinterpret_cast<const float4*>(src + lk0);
       dst[1] = *reinterpret_cast<const float4*>(src + lk1);
     };
-    const float* vg = p.V + (int64_t)grp * p.v_group_stride;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) load_raw(uraw[mi], p.U + (int64_t)(mok[mi] ? mrow[mi] : p.M - 1) * p.ldu);
 #pragma unroll
@@ -193,7 +193,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
       n = n < p.N ? n : p.N - 1;
       load_raw(vraw[ni], vg + (int64_t)n * R);
     }
-  }
+  };
+  if (LORA) load_factors(0);
 
   int t_begin = 0, t_end = nt;
   if (p.k_splits > 1) {
@@ -231,30 +232,30 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
   // ---- epilogue
   MF_STAMP(2);
   if (LORA) {
-    // branch-free conversion: `lo` and a zero scale are lane selects
-    auto conv = [&](const float4 (&raw)[2], float sc, bool lo) -> bf16x8_t {
-      const float s1 = lk0 + 4 < R ? sc : 0.f;
-      const float x[8] = {raw[0].x * sc, raw[0].y * sc, raw[0].z * sc, raw[0].w * sc,
-                          raw[1].x * s1, raw[1].y * s1, raw[1].z * s1, raw[1].w * s1};
-      union { bf16x8_t v; unsigned int w[4]; } r;
+    const float on = fq <= 2 ? 1.0f : 0.0f;
+    for (int lk0 = 0; lk0 < R; lk0 += 8) {
+      if (lk0 > 0) load_factors(lk0);
+      const float tail = lk0 + 4 < R ? 1.0f : 0.0f;
+      // branch-free conversion: `lo` and a zero scale are lane selects
+      auto conv = [&](const float4 (&raw)[2], float sc, bool lo) -> bf16x8_t {
+        const float s1 = sc * tail;
+        const float x[8] = {raw[0].x * sc, raw[0].y * sc, raw[0].z * sc, raw[0].w * sc,
+                            raw[1].x * s1, raw[1].y * s1, raw[1].z * s1, raw[1].w * s1};
+        union { bf16x8_t v; unsigned int w[4]; } r;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const unsigned int h = pack_bf16x2(x[2 * i], x[2 * i + 1]);
-        const unsigned int l = pack_bf16x2(x[2 * i] - bf16_lo(h), x[2 * i + 1] - bf16_hi(h));
-        r.w[i] = lo ? l : h;
-      }
-      return r.v;
-    };
-    const int npass = Rp == 8 ? 1 : 2;
-    for (int pass = 0; pass < npass; ++pass) {
-      const int comp = Rp == 8 ? fq : 2 * pass + (fq >> 1);      // which product this lane's 8 k-slots belong to
-      const float on = comp <= 2 ? 1.0f : 0.0f;
+        for (int i = 0; i < 4; ++i) {
+          const unsigned int h = pack_bf16x2(x[2 * i], x[2 * i + 1]);
+          const unsigned int l = pack_bf16x2(x[2 * i] - bf16_lo(h), x[2 * i + 1] - bf16_hi(h));
+          r.w[i] = lo ? l : h;
+        }
+        return r.v;
+      };
       bf16x8_t vf[4];
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) vf[ni] = conv(vraw[ni], on, comp == 2);
+      for (int ni = 0; ni < 4; ++ni) vf[ni] = conv(vraw[ni], on, fq == 2);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
-        const bf16x8_t um = conv(uraw[mi], on * p.lr_scale, comp == 1);
+        const bf16x8_t um = conv(uraw[mi], on * p.lr_scale, fq == 1);
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[ni], um, acc[ni][mi], 0, 0, 0);

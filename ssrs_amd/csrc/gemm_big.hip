@@ -297,42 +297,41 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
   const int ncol0 = n0 + wn * 16 * NF;
 
   if (LORA) {
-    // Low-rank update = extra MFMA k-steps whose 32 k-slots hold the rank index up to three times: slots [0,Rp) U_hi.V_hi,
-    // [Rp,2Rp) U_lo.V_hi, [2Rp,3Rp) U_hi.V_lo (hi = bf16(x), lo = bf16(x - hi); Rp = 8 for R <= 8 -> one k-step, else 16 -> two),
-    // as in gemm.hip. The raw fp32 factor rows are fetched here, one column group at a time (registers: NF = 9 holds 144
-    // accumulators).
-    const int R = p.R, Rp = R <= 8 ? 8 : 16;
-    const int lk0 = Rp == 8 ? 0 : 8 * (fq & 1);
-    const int lk1 = lk0 + 4 < R ? lk0 + 4 : lk0;
-    auto load_raw = [&](float4 (&dst)[2], const float* s) {
-      dst[0] = *reinterpret_cast<const float4*>(s + lk0);
-      dst[1] = *reinterpret_cast<const float4*>(s + lk1);
-    };
-    auto conv = [&](const float4 (&raw)[2], float sc, bool lo) -> bf16x8_t {
-      const float s1 = lk0 + 4 < R ? sc : 0.f;
-      const float x[8] = {raw[0].x * sc, raw[0].y * sc, raw[0].z * sc, raw[0].w * sc,
-                          raw[1].x * s1, raw[1].y * s1, raw[1].z * s1, raw[1].w * s1};
-      union { bf16x8_t v; unsigned int w[4]; } r;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const unsigned int h = pack_bf16x2(x[2 * i], x[2 * i + 1]);
-        const unsigned int l = pack_bf16x2(x[2 * i] - bf16_lo(h), x[2 * i + 1] - bf16_hi(h));
-        r.w[i] = lo ? l : h;
-      }
-      return r.v;
-    };
+    // Low-rank update = one extra MFMA k-step per 8 ranks whose 32 k-slots hold the rank index three times: slots [0,8) U_hi.V_hi,
+    // [8,16) U_lo.V_hi, [16,24) U_hi.V_lo (hi = bf16(x), lo = bf16(x - hi)), as in gemm.hip: lane quarter fq owns product fq of
+    // the pass's ranks [8*pass, 8*pass + 8). R = 4 / 8 (the default LoRA rank 4: stacked factors of 8 columns) take one pass, LoRA
+    // ranks up to 16 (R <= 32) up to four. The raw fp32 factor rows are fetched here, one column group at a time (registers:
+    // NF = 9 holds 144 accumulators).
+    const int R = p.R;
     const float* vg = p.V + (int64_t)grp * p.v_group_stride;
-    const int npass = Rp == 8 ? 1 : 2;
-    for (int pass = 0; pass < npass; ++pass) {
-      const int comp = Rp == 8 ? fq : 2 * pass + (fq >> 1);      // which product this lane's 8 k-slots belong to
-      const float on = comp <= 2 ? 1.0f : 0.0f;
+    const float on = fq <= 2 ? 1.0f : 0.0f;
+    for (int lk0 = 0; lk0 < R; lk0 += 8) {
+      const int lk1 = lk0 + 4 < R ? lk0 + 4 : lk0;
+      const float tail = lk0 + 4 < R ? 1.0f : 0.0f;
+      auto load_raw = [&](float4 (&dst)[2], const float* s) {
+        dst[0] = *reinterpret_cast<const float4*>(s + lk0);
+        dst[1] = *reinterpret_cast<const float4*>(s + lk1);
+      };
+      auto conv = [&](const float4 (&raw)[2], float sc, bool lo) -> bf16x8_t {
+        const float s1 = sc * tail;
+        const float x[8] = {raw[0].x * sc, raw[0].y * sc, raw[0].z * sc, raw[0].w * sc,
+                            raw[1].x * s1, raw[1].y * s1, raw[1].z * s1, raw[1].w * s1};
+        union { bf16x8_t v; unsigned int w[4]; } r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const unsigned int h = pack_bf16x2(x[2 * i], x[2 * i + 1]);
+          const unsigned int l = pack_bf16x2(x[2 * i] - bf16_lo(h), x[2 * i + 1] - bf16_hi(h));
+          r.w[i] = lo ? l : h;
+        }
+        return r.v;
+      };
       bf16x8_t um[4];
       {
-        float4 uraw[4][2];                                        // (re-read per pass: keeps 32 registers free beside 16*NF accumulators)
+        float4 uraw[4][2];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) load_raw(uraw[mi], p.U + (int64_t)mrow[mi] * p.ldu);
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) um[mi] = conv(uraw[mi], on * p.lr_scale, comp == 1);
+        for (int mi = 0; mi < 4; ++mi) um[mi] = conv(uraw[mi], on * p.lr_scale, fq == 1);
       }
 #pragma unroll
       for (int gi = 0; gi < C::NG; ++gi) {
@@ -347,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (i >= G) break;
-          const bf16x8_t vf = conv(vraw[i], on, comp == 2);
+          const bf16x8_t vf = conv(vraw[i], on, fq == 2);
 #pragma unroll
           for (int mi = 0; mi < 4; ++mi)
             acc[f0 + i][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, um[mi], acc[f0 + i][mi], 0, 0, 0);

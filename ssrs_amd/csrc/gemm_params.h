@@ -3,7 +3,7 @@
 #pragma once
 #include "common.h"
 
-#define GEMM_MAX_R 16
+#define GEMM_MAX_R 32
 
 struct GemmParams {
   const bf16_t* A; int64_t lda;

@@ -130,7 +130,13 @@ extern "C" int mfnet_tile_minmax_norm(float* tiles, int64_t n, int64_t per_tile,
 }
 
 // sum[row+y, col+x] += softmax(logits[t,:,y,x])[cls] ; cnt[...] += 1 over the valid extent of each tile
-__global__ __launch_bounds__(256) void tile_prob_accumulate_kernel(float* __restrict__ sum, float* __restrict__ cnt, const float* __restrict__ logits,
+// Order-independent blend: the sums are 64-bit FIXED-POINT integers (probability * 2^40, rounded once per tile in double)
+// and the tile counts integers - integer atomic adds commute, so the blended raster is bit-identical from run to run and
+// for every window order / rank count (fp32 atomics left order-dependent last bits). 2^40 resolves 9e-13, finer than fp32
+// near any probability the 0.5 threshold can see; 2^23 overlapping tiles fit before the sum could overflow.
+#define MF_PROB_FIX 1099511627776.0   /* 2^40 */
+__global__ __launch_bounds__(256) void tile_prob_accumulate_kernel(unsigned long long* __restrict__ sum, unsigned long long* __restrict__ cnt,
+                                                                   const float* __restrict__ logits,
                                                                    const int* __restrict__ coords, int64_t n, int C, int64_t W, int h, int w, int cls) {
   const int64_t per = (int64_t)h * w, total = n * per;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -146,29 +152,32 @@ __global__ __launch_bounds__(256) void tile_prob_accumulate_kernel(float* __rest
     for (int c = 0; c < C; ++c) se += __expf(lp[(int64_t)c * per] - mx);
     const float pr = __expf(lp[(int64_t)cls * per] - mx) / se;
     const int64_t o = (int64_t)(cd[0] + y) * W + cd[1] + x;
-    atomicAdd(sum + o, pr);
-    atomicAdd(cnt + o, 1.f);
+    const double q = (double)pr * MF_PROB_FIX + 0.5;
+    atomicAdd(sum + o, (pr == pr && q > 0.0) ? (unsigned long long)q : 0ull);      // (a NaN logit contributes 0, not garbage)
+    atomicAdd(cnt + o, 1ull);
   }
 }
-extern "C" int mfnet_tile_prob_accumulate(float* sum, float* cnt, const float* logits, const int* coords, int64_t n, int64_t C, int64_t H, int64_t W,
+extern "C" int mfnet_tile_prob_accumulate(int64_t* sum, int64_t* cnt, const float* logits, const int* coords, int64_t n, int64_t C, int64_t H, int64_t W,
                                           int64_t h, int64_t w, int64_t cls, hipStream_t stream) {
   MF_CHECK_ARG(sum && cnt && logits && coords && C > 0 && cls >= 0 && cls < C && h > 0 && w > 0, "tile_prob_accumulate: bad args");
+  MF_CHECK_ARG(((uintptr_t)sum | (uintptr_t)cnt) % 8 == 0, "tile_prob_accumulate: the 64-bit accumulators must be 8-byte aligned");
   if (n <= 0) return MFNET_OK;
-  hipLaunchKernelGGL(tile_prob_accumulate_kernel, dim3(grid_for(n * h * w)), dim3(256), 0, stream, sum, cnt, logits, coords, n, (int)C, W, (int)h, (int)w, (int)cls);
+  hipLaunchKernelGGL(tile_prob_accumulate_kernel, dim3(grid_for(n * h * w)), dim3(256), 0, stream, (unsigned long long*)sum, (unsigned long long*)cnt,
+                     logits, coords, n, (int)C, W, (int)h, (int)w, (int)cls);
   MF_LAUNCH_CHECK("tile_prob_accumulate");
   return MFNET_OK;
 }
 // prob = sum / cnt (0 where no tile covers the pixel) ; mask = prob >= threshold (inference.py:582)
-__global__ __launch_bounds__(256) void blend_finish_kernel(const float* __restrict__ sum, const float* __restrict__ cnt, float* __restrict__ prob,
+__global__ __launch_bounds__(256) void blend_finish_kernel(const int64_t* __restrict__ sum, const int64_t* __restrict__ cnt, float* __restrict__ prob,
                                                            unsigned char* __restrict__ mask, float thr, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float c = cnt[i];
-    const float p = c > 0.f ? sum[i] / c : 0.f;
+    const int64_t c = cnt[i];
+    const float p = c > 0 ? (float)(((double)sum[i] / MF_PROB_FIX) / (double)c) : 0.f;
     if (prob) prob[i] = p;
     if (mask) mask[i] = p >= thr ? 1 : 0;
   }
 }
-extern "C" int mfnet_blend_finish(const float* sum, const float* cnt, float* prob, unsigned char* mask, float threshold, int64_t n, hipStream_t stream) {
+extern "C" int mfnet_blend_finish(const int64_t* sum, const int64_t* cnt, float* prob, unsigned char* mask, float threshold, int64_t n, hipStream_t stream) {
   MF_CHECK_ARG(sum && cnt && (prob || mask) && n >= 0, "blend_finish: bad args");
   if (n == 0) return MFNET_OK;
   hipLaunchKernelGGL(blend_finish_kernel, dim3(grid_for(n)), dim3(256), 0, stream, sum, cnt, prob, mask, threshold, n);

@@ -179,6 +179,11 @@ def _device_add_rows(band, buf):
     ops.tile_accumulate(band, buf[None].contiguous(), coords, atomic=False)
 
 
+def _int_add_rows(band, buf):
+    """band[:, :k, :] += buf for the int64 blend accumulators (an exact integer add: nothing to round, nothing to order)."""
+    band[:, :buf.shape[1], :] += buf
+
+
 class GraphedForward:
     """`forward(rgb_tiles, dsm_tiles) -> logits` replayed from a HIP graph, one graph per input shape. The eval forward of
     MFNet is ~450 kernel launches of a few microseconds each for a 32-tile batch: enqueued eagerly from Python the host is
@@ -372,7 +377,9 @@ class RasterInference:
         wins = [wins[i] for i in order]
         plan = plan_bands([t[0] for t in wins], [t[2] - t[0] for t in wins], H, world) if wins else []
         me = plan[rank] if rank < len(plan) else dict(first=0, last=0, lo=0, hi=0, own_lo=0, own_hi=0)
-        band = torch.zeros((2, max(1, me["hi"] - me["lo"]), W), dtype=torch.float32, device=img.device)   # [prob sum ; count]
+        # [fixed-point prob sum ; tile count] as int64: integer adds commute, so the blend is bit-identical whatever the order
+        # of the windows, the atomics and the ranks (ops.tile_prob_accumulate)
+        band = torch.zeros((2, max(1, me["hi"] - me["lo"]), W), dtype=torch.int64, device=img.device)
         demc = dem.float().contiguous()
         for chunk in grouper(self.batch_size, wins[me["first"]:me["last"]]):
             c4 = _coords4([(y, x, ye - y, xe - x) for y, x, ye, xe in chunk], H, W, h, w, img.device)
@@ -384,7 +391,7 @@ class RasterInference:
             c4b[:, 0] -= me["lo"]
             ops.tile_prob_accumulate(band[0], band[1], logits, c4b.contiguous(), self.cls)
         if world > 1 and rank < len(plan):
-            merge_bands(band, plan, rank, _device_add_rows, self.group)
+            merge_bands(band, plan, rank, _int_add_rows, self.group)
         prob = torch.zeros((H, W), dtype=torch.float32, device=img.device)
         mask = torch.zeros((H, W), dtype=torch.uint8, device=img.device)
         if me["own_hi"] > me["own_lo"]:

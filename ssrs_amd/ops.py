@@ -238,17 +238,21 @@ def gemm_grouped(a, w, *, bias=None, rows_per_group, act=0, aux=None, want_pre=F
 
 def skinny_nt(x, wt, scale=1.0, out=None, rows_per_group=0):
     """out[m, j] = scale * sum_k x[m,k] wt[g(m)][j,k]; x bf16 [M,K]; wt fp32 [R,K] or [G,R,K] with
-    g(m) = m // rows_per_group (per-modality matrices) -> fp32 [M, R] (row stride a multiple of 4)."""
+    g(m) = m // rows_per_group (per-modality matrices) -> fp32 [M, R] (row stride a multiple of 4). The kernel holds up to
+    16 output columns per row tile; wider factors (LoRA ranks 12 / 16: stacked factors of 24 / 32 rows) go in column chunks."""
     _chk(x, wt, out)
     x2, M, K, ldx = _rows2d(x)
     G = wt.shape[0] if wt.dim() == 3 else 1
     R = wt.shape[-2]
-    assert wt.dtype == torch.float32 and wt.is_contiguous() and wt.shape[-1] == K
+    assert wt.dtype == torch.float32 and wt.stride(-1) == 1 and wt.shape[-1] == K
     if out is None:
         Rp = (R + 3) // 4 * 4
         out = torch.empty((M, Rp), dtype=torch.float32, device=x.device)[:, :R]
-    call("mfnet_skinny_nt", x2.data_ptr(), ldx, wt.data_ptr(), K, R * K, rows_per_group if G > 1 else 0, G, out.data_ptr(),
-         out.stride(0), M, K, R, float(scale), _stream(x))
+    for c0 in range(0, R, 16):
+        c1 = min(R, c0 + 16)
+        wc, oc = wt[..., c0:c1, :], out[:, c0:c1]
+        call("mfnet_skinny_nt", x2.data_ptr(), ldx, wc.data_ptr(), wc.stride(-2), wc.stride(0) if G > 1 else 0, rows_per_group if G > 1 else 0, G,
+             oc.data_ptr(), oc.stride(0), M, K, c1 - c0, float(scale), _stream(x))
     return out
 
 
@@ -292,14 +296,30 @@ class SplitSum:
         return out
 
 
+def _tn_chunks(R):
+    """column chunks of the widths mfnet_skinny_tn is built for (16 / 8 / 4) covering R (a multiple of 4)"""
+    out, c0 = [], 0
+    while c0 < R:
+        w = 16 if R - c0 >= 16 else (8 if R - c0 >= 8 else 4)
+        out.append((c0, c0 + w))
+        c0 += w
+    return out
+
+
 def skinny_tn(y, u, transposed: bool, scale=1.0, out=None, n_groups=1, lazy=False):
     """per group z (rows [z*M/G, (z+1)*M/G)): out[z][c, j] (or [j, c] if transposed) += scale * sum_m y[m,c] u[m,j];
     y bf16 [M,C], u fp32 [M,R]. Returns [G, C, R] / [G, R, C] (the leading dim is dropped for n_groups == 1).
-    lazy: returns a SplitSum over the partial tiles instead (no reduce launch; for gradients handed to deliver)."""
+    lazy: returns a SplitSum over the partial tiles instead (no reduce launch; for gradients handed to deliver).
+    R other than 4 / 8 / 16 (LoRA ranks 12 / 16: factors of 12, 24 or 32 columns) runs in column chunks and always returns
+    the dense tensor."""
     _chk(y, u, out)
     y2, M, C, ldy = _rows2d(y)
     R = u.shape[1]
     assert u.dtype == torch.float32 and u.stride(1) == 1 and u.shape[0] == M and M % n_groups == 0
+    if R not in (4, 8, 16):
+        assert R % 4 == 0 and out is None, f"skinny_tn: R={R} must be a multiple of 4"
+        parts = [skinny_tn(y, u[:, c0:c1], transposed, scale, None, n_groups, False) for c0, c1 in _tn_chunks(R)]
+        return torch.cat(parts, -2 if transposed else -1)
     Mg = M // n_groups
     nws = _lib.lib().mfnet_skinny_tn_workspace_floats(Mg, C, R, n_groups)
     ws = torch.empty(nws, dtype=torch.float32, device=y.device)
@@ -1153,8 +1173,10 @@ def prepare_tiles(rgb_u8, dsm, labels, codes, mean=(0.485, 0.456, 0.406), std=(0
 
 
 def tile_prob_accumulate(psum, cnt, logits, coords4, cls):
+    """psum / cnt: int64 [H, W] (psum in fixed point, probability * 2^40): integer atomics, order-independent."""
     _chk(psum, cnt, logits, coords4)
     assert psum.is_contiguous() and cnt.is_contiguous() and logits.is_contiguous() and logits.dtype == torch.float32
+    assert psum.dtype == torch.int64 and cnt.dtype == torch.int64
     H, W = psum.shape
     n, C, h, w = logits.shape
     call("mfnet_tile_prob_accumulate", psum.data_ptr(), cnt.data_ptr(), logits.data_ptr(), coords4.data_ptr(), n, C, H, W, h, w, cls, _stream(psum))
@@ -1162,7 +1184,8 @@ def tile_prob_accumulate(psum, cnt, logits, coords4, cls):
 
 def blend_finish(psum, cnt, threshold):
     _chk(psum, cnt)
-    prob = torch.empty_like(psum)
+    assert psum.dtype == torch.int64 and cnt.dtype == torch.int64 and psum.is_contiguous() and cnt.is_contiguous()
+    prob = torch.empty(psum.shape, dtype=torch.float32, device=psum.device)
     mask = torch.empty(psum.shape, dtype=torch.uint8, device=psum.device)
     call("mfnet_blend_finish", psum.data_ptr(), cnt.data_ptr(), prob.data_ptr(), mask.data_ptr(), float(threshold), psum.numel(), _stream(psum))
     return prob, mask

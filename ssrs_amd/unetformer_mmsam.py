@@ -69,12 +69,27 @@ class SeparableConvBN(nn.Sequential):
         super().__init__(_conv(cin, cin, kernel_size, groups=cin), nn.BatchNorm2d(cout), nn.Conv2d(cin, cout, 1, bias=False))
 
 
+def _only(name, value, accepted, why):
+    """The reference's constructor keywords are kept (unetformer_mmsam.py:86-88, 200-202); values the HIP kernels do not
+    implement are refused by name instead of surfacing as a TypeError or, worse, being ignored."""
+    if value not in accepted:
+        raise NotImplementedError(f"{name}={value!r}: the HIP path implements {why} (what MFNet uses)")
+
+
 class Mlp(nn.Module):
-    def __init__(self, dim, hidden):
+    """unetformer_mmsam.py:86-102: `Mlp(in_features, hidden_features=None, out_features=None, act_layer=nn.ReLU6, drop=0.)`."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.ReLU6, drop=0.):
         super().__init__()
-        self.fc1 = nn.Conv2d(dim, hidden, 1, 1, 0, bias=True)
-        self.act = nn.ReLU6()
-        self.fc2 = nn.Conv2d(hidden, dim, 1, 1, 0, bias=True)
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        _only("act_layer", act_layer, (nn.ReLU6,), "the fused ReLU6 epilogue")
+        _only("drop", float(drop), (0.0,), "drop=0")
+        _only("out_features", out_features, (in_features,), "out_features == in_features (the residual form)")
+        self.fc1 = nn.Conv2d(in_features, hidden_features, 1, 1, 0, bias=True)
+        self.act = act_layer()
+        self.fc2 = nn.Conv2d(hidden_features, out_features, 1, 1, 0, bias=True)
+        self.drop = nn.Dropout(drop, inplace=True)          # p = 0: an identity kept for the attribute surface (no parameters)
 
     @torch.no_grad()
     def forward(self, x):
@@ -116,12 +131,20 @@ class GlobalLocalAttention(nn.Module):
 
 
 class Block(nn.Module):
-    def __init__(self, dim=256, num_heads=16, mlp_ratio=4., window_size=8):
+    """unetformer_mmsam.py:200-217, with the reference's keyword surface."""
+
+    def __init__(self, dim=256, num_heads=16, mlp_ratio=4., qkv_bias=False, drop=0., attn_drop=0., drop_path=0., act_layer=nn.ReLU6,
+                 norm_layer=nn.BatchNorm2d, window_size=8):
         super().__init__()
-        self.norm1 = nn.BatchNorm2d(dim)
-        self.attn = GlobalLocalAttention(dim, num_heads=num_heads, qkv_bias=False, window_size=window_size)
-        self.mlp = Mlp(dim, int(dim * mlp_ratio))
-        self.norm2 = nn.BatchNorm2d(dim)
+        _only("qkv_bias", bool(qkv_bias), (False,), "a bias-free qkv conv")
+        _only("attn_drop", float(attn_drop), (0.0,), "attn_drop=0 (the reference's Block never passes it on either)")
+        _only("drop_path", float(drop_path), (0.0,), "drop_path=0")
+        _only("norm_layer", norm_layer, (nn.BatchNorm2d,), "BatchNorm2d")
+        self.norm1 = norm_layer(dim)
+        self.attn = GlobalLocalAttention(dim, num_heads=num_heads, qkv_bias=qkv_bias, window_size=window_size)
+        self.drop_path = nn.Identity()
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), out_features=dim, act_layer=act_layer, drop=drop)
+        self.norm2 = norm_layer(dim)
 
     def forward_rows(self, x, geom):
         """x fp32 [B*H*W, C] channels-last rows."""

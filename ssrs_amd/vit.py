@@ -360,8 +360,10 @@ class LoRALayer:
 
 
 def _check_rank(r):
-    if r not in (2, 4, 8):
-        raise ValueError(f"LoRA rank {r} unsupported by the HIP path (use 2, 4 or 8; default 4)")
+    """`-mid_dim` (lora_block.py:44-47, medsam/cfg.py:47). Ranks 4 and 8 take the fused LayerNorm / row-streaming side kernels;
+    2, 12 and 16 the general skinny products (the GEMM epilogue adds up to 32 stacked rank columns, 8 per extra k-step)."""
+    if r not in (2, 4, 8, 12, 16):
+        raise ValueError(f"LoRA rank {r} unsupported by the HIP path (use 2, 4, 8, 12 or 16; default 4)")
 
 
 class Linear(nn.Linear, LoRALayer):

@@ -126,7 +126,7 @@ def test_gemm_identity_asymmetric(ops):
     assert torch.equal(out, w.float().t().contiguous())
 
 
-@pytest.mark.parametrize("R,G", [(8, 1), (8, 2), (4, 2), (16, 1)])
+@pytest.mark.parametrize("R,G", [(8, 1), (8, 2), (4, 2), (16, 1), (24, 2), (32, 2)])
 def test_gemm_lowrank_gelu_residual(ops, R, G):
     M, N, K = 1024, 768, 768
     a = rnd(M, K, seed=1).to(torch.bfloat16)
@@ -200,6 +200,11 @@ def test_gemm_tile_shapes_all_epilogues(ops, tile, N, K):
     U4, V4 = rnd(M, 4, seed=10), rnd(N, 4, seed=11)
     out = ops.gemm(a, w, U=U4, V=V4, out_dtype=torch.float32, tile=tile)
     assert rel_err(out, base + U4.double() @ V4.double().t()) < 2e-5
+    for Rw in (12, 24, 32):              # LoRA ranks 12 / 16: up to 32 stacked rank columns, 8 per extra k-step of the epilogue
+        Uw, Vw = rnd(M, Rw, seed=20 + Rw), rnd(2, N, Rw, seed=21 + Rw)
+        loww = torch.cat([Uw[g * 256:(g + 1) * 256].double() @ Vw[g].double().t() for g in range(2)]) * 0.5
+        out = ops.gemm(a, w, U=Uw, V=Vw, rows_per_group=256, n_groups=2, lr_scale=0.5, out_dtype=torch.float32, tile=tile)
+        assert rel_err(out, base + loww) < 2e-5, Rw
     pos = rnd(256, N, seed=12)
     out = ops.gemm(a, w, residual=pos, res_row_mod=256, out_dtype=torch.float32, tile=tile)
     assert rel_err(out, base + pos.double().repeat(2, 1)) < 1e-5
@@ -237,8 +242,8 @@ def test_gemm_rejects_bad_shapes(ops):
 
 
 # ------------------------------------------------------------------------------------------ skinny / lora
-@pytest.mark.parametrize("M,K,R", [(8192, 768, 8), (4100, 3072, 4), (100, 128, 16)])
-def test_skinny(ops, M, K, R):
+@pytest.mark.parametrize("M,K,R", [(8192, 768, 8), (4100, 3072, 4), (100, 128, 16), (1024, 768, 24), (800, 384, 32), (512, 128, 12)])
+def test_skinny(ops, M, K, R):          # R = 12 / 24 / 32: the column-chunked forms (LoRA ranks 12 / 16)
     x = rnd(M, K, seed=1).to(torch.bfloat16)
     wt = rnd(R, K, seed=2)
     out = ops.skinny_nt(x, wt, scale=0.5)
