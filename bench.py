@@ -177,6 +177,9 @@ def main():
     for _ in range(max(a.warmup, 3 if eng.use_graph else 0)):      # graph mode: 2 eager steps + the capture are never timed
         acc = eng.step(rgb, dsm, tgt)
     sync()
+    exchanging = dist.is_initialized() and (world > 1 or rehearsal == "nccl1")
+    if exchanging:
+        eng.exchange_events = []            # one event pair per step around the gradient collectives (2 event records: no sync)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         acc = eng.step(rgb, dsm, tgt)
@@ -187,6 +190,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     metrics = TrainEngine.read_metrics(acc)
+    comm = None
+    if exchanging:
+        # makes the N > 1 record self-proving: which backend exchanged, over how many ranks, how many bytes, how long per step
+        evs, eng.exchange_events = eng.exchange_events, None
+        torch.cuda.synchronize()
+        ar_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, len(evs))
+        comm = {"backend": dist.get_backend(), "rccl_world": dist.get_world_size(), "grad_bytes": eng.grad_bytes,
+                "allreduce_ms_per_step": round(ar_ms, 4), "allreduces_timed": len(evs),
+                "exchange": "one all-reduce of the flat gradient buffer after the graph replay" if eng.use_graph
+                            else "two buckets launched from the backward pass (overlapped)"}
 
     roofline = roofline_all = roofline_hbm = None
     if not a.no_roofline:
@@ -279,6 +292,8 @@ def main():
             out["roofline_all_gemm"] = roofline_all
         if roofline_hbm is not None:
             out["roofline_hbm"] = roofline_hbm
+        if comm is not None:
+            out["comm"] = comm
         if rehearsal:
             out["rehearsal"] = rehearsal + ": control-flow check only, not a measurement"
         if world == 1 and not a.no_cpu:

@@ -9,8 +9,13 @@ returns a persistent tensor that `ParamBank.refresh()` re-fills from the current
 `mfnet_gather_segments` launches at the start of every step (inside the captured HIP graph in graph mode).
 The first time a key is seen it is built on the spot and registered. Without an active bank and with autograd on
 (plain module calls, autograd tests) every call builds a fresh tensor; under no_grad (inference, evaluation between
-steps) the tensor is kept and validated against its sources' version counters and WEIGHTS_EPOCH on every call, so
-stale weights are impossible either way.
+steps) the tensor is kept and validated against its sources' version counters and WEIGHTS_EPOCH on every call. What that
+check sees: every in-place torch op on a parameter (load_state_dict, optimizer steps, `p.mul_()`), and whoever calls
+`weights_changed()`. What it does NOT see: writes through `p.data` (`p.data.mul_()`, `p.data.copy_()` - `.data` is a tensor
+with a version counter of its own) - such code must call `weights_changed()` itself, as TrainEngine's SGD kernel and broadcast do -
+and a parameter re-pointed to new storage (`p.data = new`, `model.to()`): the stored source views keep the old storage alive, so
+the comparison passes; `inference.GraphedForward` fingerprints the parameter addresses before every replay for that case and
+drops its graphs and this store when they moved.
 
 deliver - a parameter the engine adopted carries `_mfnet_sink = (grad_view, notify)`: its gradient, in
 whatever strided layout the kernels produced it, is added into the flat gradient buffer by the same gather

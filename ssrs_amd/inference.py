@@ -191,13 +191,35 @@ class GraphedForward:
     attributes, which must not happen under capture); the next one captures. The returned tensor is the graph's static
     output: it is overwritten by the next call of the same shape, so consume it first (the predictors below do)."""
 
-    def __init__(self, forward: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], warmup: int = 1):
+    def __init__(self, forward: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], warmup: int = 1, model=None):
+        """model: the nn.Module(s) whose parameters the forward reads; found from the callable itself (a bound method, or a
+        closure over a module / an object with a `.model`) when not given. Their parameter and buffer ADDRESSES are part of
+        what a captured graph froze, so they are fingerprinted before every replay: a re-pointed parameter (`p.data = new`,
+        `model.to(...)`, a TrainEngine adopting the model into its flat buffer) drops the graphs and the operand store instead
+        of replaying against the old addresses."""
         self.forward, self.warmup = forward, warmup
         self._graphs, self._seen = {}, {}
+        self._modules = _modules_of(forward) if model is None else ([model] if isinstance(model, torch.nn.Module) else list(model))
+        self._print = None
+
+    def _fingerprint(self):
+        fp = []
+        for m in self._modules:
+            fp += [t.data_ptr() for t in m.parameters()]
+            fp += [t.data_ptr() for t in m.buffers()]
+        return tuple(fp)
 
     @torch.no_grad()
     def __call__(self, rgb: torch.Tensor, dsm: torch.Tensor) -> torch.Tensor:
         key = (tuple(rgb.shape), tuple(dsm.shape), rgb.dtype, dsm.dtype, rgb.device)
+        if self._graphs and self._modules:
+            fp = self._fingerprint()
+            if fp != self._print:             # storage moved since the capture: nothing captured or stored may be used again
+                self._graphs.clear()
+                self._seen.clear()
+                if EvalBank.active is not None:
+                    EvalBank.active.entries.clear()
+                    EvalBank.active.bn.clear()
         ent = self._graphs.get(key)
         if ent is None:
             n = self._seen.get(key, 0)
@@ -210,6 +232,7 @@ class GraphedForward:
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 out = self.forward(srgb, sdsm)
             ent = self._graphs[key] = (g, srgb, sdsm, out)
+            self._print = self._fingerprint() if self._modules else None
         g, srgb, sdsm, out = ent
         if EvalBank.active is not None:
             EvalBank.active.validate()        # the graph reads the stored weight-derived operands: refreshed in place if stale
@@ -217,6 +240,21 @@ class GraphedForward:
         sdsm.copy_(dsm, non_blocking=True)
         g.replay()
         return out
+
+
+def _modules_of(fn):
+    """nn.Modules a forward callable reaches: itself / its bound object, and whatever its closure holds (directly or as `.model`)."""
+    found, cand = [], [fn, getattr(fn, "__self__", None)]
+    for cell in getattr(fn, "__closure__", None) or ():
+        try:
+            cand.append(cell.cell_contents)
+        except ValueError:
+            pass
+    for c in cand:
+        for o in (c, getattr(c, "model", None)):
+            if isinstance(o, torch.nn.Module) and all(o is not f for f in found):
+                found.append(o)
+    return found
 
 
 # ---------------------------------------------------------------------------------------------- evaluator-style

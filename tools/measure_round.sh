@@ -4,9 +4,10 @@
 # -> gpurun_out/<tag>/: bench.json, kernel stats csv, PMC traffic JSONs (GEMM + ln_bwd). Each GPU step has its own time limit.
 set -e -o pipefail
 TAG=${1:-rXX}
-OUT=gpurun_out/$TAG
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 timeout -k 10 300 python bench.py --steps 30 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks -o $TAG -- python3 bench.py --steps 20 --warmup 3 --no-cpu --no-roofline > $OUT/bench_under_rocprof.json 2> $OUT/ks.err
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_f -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-roofline --eager > /dev/null 2> $OUT/pmc_f.err
