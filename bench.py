@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a HIP graph")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the with_h2d leg (steps fed from pinned host memory through the prefetcher)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -201,7 +202,39 @@ def main():
                 "exchange": "one all-reduce of the flat gradient buffer after the graph replay" if eng.use_graph
                             else "two buckets launched from the backward pass (overlapped)"}
 
-    roofline = roofline_all = roofline_hbm = None
+    with_h2d = None
+    if not a.no_h2d and a.tile == 256:
+        # The same step fed the way a loader feeds it: raw uint8 RGB + fp32 DSM + int64 labels in HOST memory, staged through
+        # pinned buffers and copied one batch ahead on a side stream (ssrs_amd.data.Prefetcher), augmented / normalised on the
+        # device (DeviceAugment: flips, rot90, brightness / contrast jitter, ImageNet statistics, per-tile DSM min-max). A
+        # reported leg beside `value`, whose timed region starts with the batch resident in HBM.
+        from ssrs_amd.data import DeviceAugment, Prefetcher
+        hsteps = min(a.steps, 50)
+        g = torch.Generator().manual_seed(1234 + rank)
+        host_rgb = torch.randint(0, 256, (a.batch, 3, a.tile, a.tile), dtype=torch.uint8, generator=g)
+        host_dsm = 100 + 20 * torch.rand((a.batch, a.tile, a.tile), generator=g)
+        host_tgt = tgt.cpu()
+        aug = DeviceAugment(generator=g)
+        feed = Prefetcher(((host_rgb, host_dsm, host_tgt) for _ in range(hsteps + 3)), device=dev, transform=aug)
+        itr = iter(feed)
+        for _ in range(3):
+            eng.step(*next(itr))
+        sync()
+        th = time.perf_counter()
+        for batch in itr:
+            eng.step(*batch)
+        sync()
+        dth = time.perf_counter() - th
+        if world > 1:
+            t = torch.tensor([dth], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dth = t.item()
+        nbytes = host_rgb.numel() + host_dsm.numel() * 4 + host_tgt.numel() * 8
+        with_h2d = {"ms_per_step": round(1e3 * dth / hsteps, 3), "tiles_per_s": round(world * a.batch * hsteps / dth, 2), "steps": hsteps,
+                    "h2d_bytes_per_step_per_gpu": int(nbytes),
+                    "pipeline": "pinned double-buffered prefetch (side stream) + device flip/rot90/jitter/normalise/DSM min-max + train step"}
+
+    roofline = roofline_all = roofline_hbm = roofline_attn = roofline_hbm_table = None
     if not a.no_roofline:
         # second pass over the same steps, eagerly, with an event pair around every GEMM launch. Every rank takes
         # it (the steps contain the gradient all-reduce, a collective); rank 0's launches are the ones reported.
@@ -213,6 +246,13 @@ def main():
         torch.cuda.synchronize()
         tr, ops.GEMM_TRACE = ops.GEMM_TRACE, None
         tr_ln, ops.LN_BWD_TRACE = ops.LN_BWD_TRACE, None
+        # third pass, a few steps: every other traced entry point (the HBM-bound kernels and attention), see ops.tcall
+        ops.KERNEL_TRACE = {}
+        ksteps = min(a.steps, 5)
+        for _ in range(ksteps):
+            eng.step(rgb, dsm, tgt)
+        torch.cuda.synchronize()
+        ktr, ops.KERNEL_TRACE = ops.KERNEL_TRACE, None
     if rank == 0 and not a.no_roofline:
         # an event pair with nothing between its two records still reads a few microseconds apart; that offset
         # (median of 64 empty pairs) is taken off every launch so the figure agrees with rocprofv3's kernel durations
@@ -264,6 +304,33 @@ def main():
             roofline_hbm = {"bound": "hbm", "kernel": "ln_bwd_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic_ln, "launches_per_step": len(tr_ln) // rsteps,
                             "avg_launch_us": round(1e3 * ms_ln / len(tr_ln), 2), "mbytes_per_launch": round(by_ln / len(tr_ln) / 1e6, 2)}
+        # attention (MFMA-bound by its arithmetic, issue-bound in practice) and the ten largest HBM-bound kernels of the step:
+        # algorithmic FLOPs / bytes (each operand once) over live event-pair durations
+        def kagg(name):
+            ent = ktr.get(name, [])
+            ms = sum(max(e0.elapsed_time(e1) - ev_over, 0.0) for e0, e1, _, _ in ent)
+            return ent, ms, sum(t[2] for t in ent), sum(t[3] for t in ent)
+        roofline_attn = {}
+        for nm in ("mfnet_attn_fwd", "mfnet_attn_bwd"):
+            ent, ms, _, fl = kagg(nm)
+            if ent and ms > 0:
+                tf = fl / (ms * 1e-3) / 1e12
+                roofline_attn[nm] = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "launches_per_step": len(ent) // ksteps,
+                                     "avg_launch_us": round(1e3 * ms / len(ent), 2), "gflop_per_launch": round(fl / len(ent) / 1e9, 3),
+                                     "ms_per_step": round(ms / ksteps, 3)}
+        hbm_rows = []
+        for nm in ktr:
+            ent, ms, by, fl = kagg(nm)
+            if nm.startswith("mfnet_attn") or not ent or ms <= 0 or by <= 0:
+                continue
+            gbs = by / (ms * 1e-3) / 1e9
+            hbm_rows.append({"kernel": nm, "launches_per_step": round(len(ent) / ksteps, 1), "avg_launch_us": round(1e3 * ms / len(ent), 2),
+                             "mbytes_per_launch": round(by / len(ent) / 1e6, 3), "achieved": round(gbs, 1), "unit": "GB/s",
+                             "frac": round(gbs / HBM_PEAK_GBS, 4), "ms_per_step": round(ms / ksteps, 4)})
+        hbm_rows.sort(key=lambda r: -r["ms_per_step"])
+        roofline_hbm_table = {"bound": "hbm", "peak": HBM_PEAK_GBS, "rows": hbm_rows[:12],
+                              "note": "algorithmic bytes (each operand once) / live event time, eager pass; small maps are launch-latency bound"}
         if os.environ.get("MFNET_GEMM_SHAPES"):          # developer aid: per-shape GEMM time on stderr
             agg = {}
             for e0, e1, f, shp in tr:
@@ -292,6 +359,11 @@ def main():
             out["roofline_all_gemm"] = roofline_all
         if roofline_hbm is not None:
             out["roofline_hbm"] = roofline_hbm
+        if not a.no_roofline:
+            out["roofline_attn"] = roofline_attn
+            out["roofline_hbm_table"] = roofline_hbm_table
+        if with_h2d is not None:
+            out["with_h2d"] = with_h2d
         if comm is not None:
             out["comm"] = comm
         if rehearsal:

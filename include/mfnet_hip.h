@@ -446,6 +446,10 @@ int mfnet_tile_minmax_norm(float* tiles, int64_t n, int64_t per_tile, int keep_f
 int mfnet_prepare_tiles(const unsigned char* rgb, const float* dsm, const int64_t* labels, const int* codes,
                         float* rgb_out, float* dsm_out, int64_t* labels_out, int64_t n, int64_t S,
                         const float* mean3, const float* std3, hipStream_t stream);
+/* Brightness / contrast jitter of the loader's augmentation (multiscale_dataset.py:250-265) in place on uint8 patches
+ * [n,3,S,S]: per tile t and channel, v = x * b; v = (v - mean(v)) * c + mean(v); clip to [0, 255]; truncate to uint8, fp32 in the
+ * reference's statement order; params [n,2] fp32 on the device = (b, c) per tile, b <= 0 leaves the tile untouched. */
+int mfnet_jitter_tiles(unsigned char* rgb, const float* params, int64_t n, int64_t S, hipStream_t stream);
 int mfnet_tile_prob_accumulate(int64_t* sum, int64_t* cnt, const float* logits, const int* coords, int64_t n, int64_t C, int64_t H,
                                int64_t W, int64_t h, int64_t w, int64_t cls, hipStream_t stream);
 int mfnet_normalize_raster(const void* in, int in_kind, int64_t C, int64_t H, int64_t W, int is_rgb, int clip, float sub,

@@ -521,6 +521,18 @@ def augment_patch(data, dsm, label, hflip, vflip, rot_k):
     return data, dsm, label
 
 
+def jitter_patch(data, brightness, contrast):
+    """(:250-265) brightness / contrast jitter of a uint8 patch [3,S,S], the reference's fp32 statements in its order."""
+    import numpy as np
+    p = data.astype(np.float32)
+    for c in range(3):
+        p[c] = p[c] * brightness
+        m = p[c].mean()
+        p[c] = (p[c] - m) * contrast + m
+        p[c] = np.clip(p[c], 0, 255)
+    return p.astype(data.dtype)
+
+
 def normalise_patch(data, dsm, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
     """(:199-208) RGB / 255 then per-channel (x - mean) / std; DSM min-max to [0,1] when max > min."""
     import numpy as np

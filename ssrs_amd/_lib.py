@@ -111,6 +111,7 @@ _SIGS = {
     "mfnet_normalize_rgb_u8": [P, P, I64, I64, F, P, P, P],
     "mfnet_extract_tiles": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, P],
     "mfnet_tile_minmax_norm": [P, I64, I64, I, P],
+    "mfnet_jitter_tiles": [P, P, I64, I64, P],
     "mfnet_tile_prob_accumulate": [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, P],
     "mfnet_blend_finish": [P, P, P, P, F, I64, P],
     "mfnet_normalize_raster": [P, I, I64, I64, I64, I, I, F, F, P, P, I, D, P, P, P],

@@ -340,3 +340,42 @@ extern "C" int mfnet_prepare_tiles(const unsigned char* rgb, const float* dsm, c
   MF_LAUNCH_CHECK("prepare_tiles");
   return MFNET_OK;
 }
+
+// ----------------------------------------------------------------------------------------------------------
+// Brightness / contrast jitter of the training loader (multiscale_dataset.py:250-265), on the raw uint8 patches, per tile and
+// RGB channel, in the reference's fp32 statement order:
+//   v = x * brightness ; m = mean(v) ; v = (v - m) * contrast + m ; v = clip(v, 0, 255) ; x = (uint8) v   (truncation)
+// params[t] = (brightness, contrast); brightness <= 0 leaves tile t untouched (the p = 0.3 "no jitter" draw). One workgroup
+// per (tile, channel): pass 1 sums the fp32 products in double (exact: <= 2^24 values below 2^9 with 24-bit mantissas), pass 2
+// applies. numpy's mean adds the same fp32 products pairwise in fp32; the two means differ in the last fp32 bits, which moves a
+// pixel that lands within ~1e-5 of an integer by one grey level (tests bound it: <= 1 level on < 0.1 % of the pixels).
+__global__ __launch_bounds__(256) void jitter_tiles_kernel(unsigned char* __restrict__ rgb, const float* __restrict__ params, int64_t per) {
+  __shared__ double red[256];
+  const int64_t tc = blockIdx.x;                       // tile * 3 + channel
+  const float b = params[2 * (tc / 3)], c = params[2 * (tc / 3) + 1];
+  if (!(b > 0.f)) return;
+  unsigned char* p = rgb + tc * per;
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < per; i += 256) s += (double)((float)p[i] * b);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float m = (float)(red[0] / (double)per);
+  for (int64_t i = threadIdx.x; i < per; i += 256) {
+    float v = (float)p[i] * b;
+    v = (v - m) * c + m;
+    v = fminf(fmaxf(v, 0.f), 255.f);
+    p[i] = (unsigned char)v;
+  }
+}
+extern "C" int mfnet_jitter_tiles(unsigned char* rgb, const float* params, int64_t n, int64_t S, hipStream_t stream) {
+  MF_CHECK_ARG(rgb && params && S > 0 && S <= 4096, "jitter_tiles: bad args");
+  if (n <= 0) return MFNET_OK;
+  MF_CHECK_ARG(n * 3 < (1ll << 31), "jitter_tiles: too many tiles");
+  hipLaunchKernelGGL(jitter_tiles_kernel, dim3((unsigned)(n * 3)), dim3(256), 0, stream, rgb, params, S * S);
+  MF_LAUNCH_CHECK("jitter_tiles");
+  return MFNET_OK;
+}

@@ -22,6 +22,23 @@ _DT = {torch.float32: F32, torch.bfloat16: BF16}
 GEMM_TRACE = None
 # likewise for the dominant HBM-bound kernel (ln_bwd_kernel): entries are (start_event, end_event, algorithmic_bytes)
 LN_BWD_TRACE = None
+# KERNEL_TRACE: when a dict, every entry point launched through tcall() is bracketed by an event pair on its stream and
+# appends (ev0, ev1, algorithmic bytes, algorithmic flops) under its name - bench.py's roofline tables (the HBM-bound kernels
+# against 8 TB/s, attention against the MFMA peak). None (the default) costs one comparison per call.
+KERNEL_TRACE = None
+
+
+def tcall(name, nbytes, flops, *args):
+    """call(name, *args) with its algorithmic bytes / flops noted for KERNEL_TRACE (each operand counted once)."""
+    if KERNEL_TRACE is None:
+        return call(name, *args)
+    st = torch.cuda.current_stream()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(st)
+    r = call(name, *args)
+    ev1.record(st)
+    KERNEL_TRACE.setdefault(name, []).append((ev0, ev1, float(nbytes), float(flops)))
+    return r
 
 
 def _stream(t: torch.Tensor):
@@ -57,7 +74,8 @@ def layernorm_fwd(x, gamma, beta, eps, out_dtype=torch.bfloat16, want_stats=True
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
-    call("mfnet_layernorm_fwd", x2.data_ptr(), _DT[x.dtype], ldx, gamma.data_ptr(), beta.data_ptr(),
+    tcall("mfnet_layernorm_fwd", rows * C * (x.element_size() + y.element_size()) + rows * 8, 0,
+          x2.data_ptr(), _DT[x.dtype], ldx, gamma.data_ptr(), beta.data_ptr(),
          y.data_ptr(), _DT[out_dtype], C, _p(mean), _p(rstd), rows, C, float(eps), _stream(x))
     return y, mean, rstd
 
@@ -74,7 +92,7 @@ def layernorm_fwd_lora(x, gamma, beta, eps, A, wx=None, wy=None):
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     a = torch.empty((rows, R), dtype=torch.float32, device=x.device)
     U = torch.empty((rows, 2 * R), dtype=torch.float32, device=x.device) if wx is not None else None
-    call("mfnet_layernorm_fwd_lora", x2.data_ptr(), _DT[x.dtype], ldx, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), C, mean.data_ptr(),
+    tcall("mfnet_layernorm_fwd_lora", rows * C * (x.element_size() + 2) + rows * (8 + 4 * R + (8 * R if U is not None else 0)), 0, x2.data_ptr(), _DT[x.dtype], ldx, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), C, mean.data_ptr(),
          rstd.data_ptr(), rows, C, float(eps), A.data_ptr(), R * C, G, R, a.data_ptr(), _p(wx), _p(wy), _p(U), _stream(x))
     return y, mean, rstd, a, U
 
@@ -88,7 +106,7 @@ def lora_down_mix(x, A, wx=None, wy=None):
     G, R = A.shape[0], A.shape[1]
     a = torch.empty((rows, R), dtype=torch.float32, device=x.device)
     U = torch.empty((rows, 2 * R), dtype=torch.float32, device=x.device) if wx is not None else None
-    call("mfnet_lora_down_mix", x2.data_ptr(), ldx, rows, C, A.data_ptr(), R * C, G, R, a.data_ptr(), _p(wx), _p(wy), _p(U), _stream(x))
+    tcall("mfnet_lora_down_mix", rows * C * 2 + rows * (4 * R + (8 * R if U is not None else 0)), 0, x2.data_ptr(), ldx, rows, C, A.data_ptr(), R * C, G, R, a.data_ptr(), _p(wx), _p(wy), _p(U), _stream(x))
     return a, U
 
 
@@ -108,13 +126,13 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, want_f32=True, want_bf16=
     if LN_BWD_TRACE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record(torch.cuda.current_stream(x.device))
-    call("mfnet_layernorm_bwd", dy2.data_ptr(), _DT[dy.dtype], lddy, x2.data_ptr(), _DT[x.dtype], ldx,
+    per_el = dy.element_size() + x.element_size() + (4 if dres is not None else 0) + (4 if want_f32 else 0) + (2 if want_bf16 else 0)
+    tcall("mfnet_layernorm_bwd", rows * C * per_el + rows * 8, 0, dy2.data_ptr(), _DT[dy.dtype], lddy, x2.data_ptr(), _DT[x.dtype], ldx,
          mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), _p(dres), _p(dx), _p(dxb), C,
          None if split_w else _p(dgamma), None if split_w else _p(dbeta), rows, C, _stream(x))
     if LN_BWD_TRACE is not None:
         ev1.record(torch.cuda.current_stream(x.device))
         # every operand is streamed once: dy, x (+ the residual gradient) in, dx (fp32 and / or bf16) out, the row statistics
-        per_el = dy.element_size() + x.element_size() + (4 if dres is not None else 0) + (4 if want_f32 else 0) + (2 if want_bf16 else 0)
         LN_BWD_TRACE.append((ev0, ev1, rows * C * per_el + rows * 8, (rows, C)))
     if split_w:
         ws, tk = _colreduce_ws(1, rows, C, x.device)
@@ -401,7 +419,7 @@ def im2col_patch(rgb, dsm, patch=16):
     if tuple(dsm.shape) != ((B, H, W) if dsm.dim() == 3 else (B, ych, H, W)) or rgb.shape[1] != 3 or ych not in (1, 3):
         raise ValueError(f"im2col_patch: rgb {tuple(rgb.shape)} and second modality {tuple(dsm.shape)} do not match")
     cols = torch.empty((2 * B * (H // patch) * (W // patch), 3 * patch * patch), dtype=torch.bfloat16, device=rgb.device)
-    call("mfnet_im2col_patch", rgb.data_ptr(), dsm.data_ptr(), ych, cols.data_ptr(), B, H, W, patch, _stream(rgb))
+    tcall("mfnet_im2col_patch", (rgb.numel() + dsm.numel()) * 4 + cols.numel() * 2, 0, rgb.data_ptr(), dsm.data_ptr(), ych, cols.data_ptr(), B, H, W, patch, _stream(rgb))
     return cols
 
 
@@ -504,7 +522,8 @@ def lora_side(y, U=None, Vt=None, n_groups=1, scale=1.0):
         # the column product alone (dA = x^T . da): nothing but the gradient delivery reads it - collected like the wgrad GEMMs
         _tn_enqueue((y2.data_ptr(), ldy, Mg, C, n_groups, U.data_ptr(), U.stride(0), dv.data_ptr()), (y2, U, dv), kind=("ls", R))
     else:
-        call("mfnet_lora_side", y2.data_ptr(), ldy, Mg, C, n_groups, _p(U), U.stride(0) if U is not None else 0, R, _p(dv),
+        tcall("mfnet_lora_side", M * C * 2 + (pp.numel() * 4 if pp is not None else 0) + (dv.numel() * 4 if dv is not None else 0), 0,
+              y2.data_ptr(), ldy, Mg, C, n_groups, _p(U), U.stride(0) if U is not None else 0, R, _p(dv),
              _p(Vt), ldvt, vgs, RP, _p(pp), _stream(y))
     if dv is not None:
         dv = SplitSum(dv.transpose(0, 1), scale)               # [splits, G, C, R], summed (x scale) by the gradient delivery
@@ -532,7 +551,10 @@ def attn_fwd(qkv, qkv_bias, tbl, G, Sh, Sw, heads, ws, Lh, Lw, scale):
     assert qkv.is_contiguous() and tbl.is_contiguous() and tbl.dtype == torch.bfloat16
     out = torch.empty((qkv.shape[0], D), dtype=torch.bfloat16, device=qkv.device)
     lse = torch.empty((G, heads, Sh * Sw), dtype=torch.float32, device=qkv.device)
-    call("mfnet_attn_fwd", qkv.data_ptr(), qkv_bias.data_ptr(), tbl.data_ptr(), out.data_ptr(), lse.data_ptr(),
+    nk = (ws * ws if ws > 0 else Sh * Sw)
+    kk = (2 * ws if ws > 0 else Sh + Sw)
+    fl = 4.0 * G * heads * Sh * Sw * nk * hd + 2.0 * G * heads * Sh * Sw * kk * hd      # QK^T + PV over real queries x window keys, + the rel-pos products
+    tcall("mfnet_attn_fwd", qkv.numel() * 2 + out.numel() * 2, fl, qkv.data_ptr(), qkv_bias.data_ptr(), tbl.data_ptr(), out.data_ptr(), lse.data_ptr(),
          G, Sh, Sw, heads, hd, ws, Lh, Lw, tbl.shape[0], float(scale), _stream(qkv))
     return out, lse
 
@@ -545,7 +567,10 @@ def attn_bwd(qkv, qkv_bias, tbl, tblT, out, dout, lse, G, Sh, Sw, heads, ws, Lh,
     dqkv = torch.empty_like(qkv)
     nws = int(_lib.lib().mfnet_attn_bwd_workspace_floats(G, Sh, Sw, heads, ws))
     wsp = torch.empty(nws, dtype=torch.float32, device=qkv.device) if nws else None
-    call("mfnet_attn_bwd", qkv.data_ptr(), qkv_bias.data_ptr(), tbl.data_ptr(), tblT.data_ptr(), out.data_ptr(),
+    nk = (ws * ws if ws > 0 else Sh * Sw)
+    kk = (2 * ws if ws > 0 else Sh + Sw)
+    fl = 2.0 * (4.0 * G * heads * Sh * Sw * nk * hd + 2.0 * G * heads * Sh * Sw * kk * hd)      # backward = 2 x forward
+    tcall("mfnet_attn_bwd", qkv.numel() * 2 * 2 + out.numel() * 2 * 2, fl, qkv.data_ptr(), qkv_bias.data_ptr(), tbl.data_ptr(), tblT.data_ptr(), out.data_ptr(),
          dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), G, Sh, Sw, heads, hd, ws, Lh, Lw, tbl.shape[0],
          float(scale), _p(wsp), nws, _stream(qkv))
     return dqkv
@@ -559,7 +584,7 @@ def ce_loss_fwd(logits, target, weight=None, ignore_index=-100, want_pred=False)
     HW = logits.numel() // (B * C)
     acc = torch.zeros(4, dtype=torch.float32, device=logits.device)   # sum w*nll, sum w, #correct, #valid
     pred = torch.empty((B,) + tuple(logits.shape[2:]), dtype=torch.uint8, device=logits.device) if want_pred else None
-    call("mfnet_ce_loss_fwd", logits.data_ptr(), target.data_ptr(), _p(weight), acc.data_ptr(), _p(pred),
+    tcall("mfnet_ce_loss_fwd", logits.numel() * 4 + target.numel() * 8, 0, logits.data_ptr(), target.data_ptr(), _p(weight), acc.data_ptr(), _p(pred),
          B, C, HW, ignore_index, _stream(logits))
     return acc, pred
 
@@ -568,7 +593,7 @@ def ce_loss_bwd(logits, target, acc, weight=None, ignore_index=-100, gscale=1.0)
     B, C = logits.shape[:2]
     HW = logits.numel() // (B * C)
     d = torch.empty_like(logits)
-    call("mfnet_ce_loss_bwd", logits.data_ptr(), target.data_ptr(), _p(weight), acc.data_ptr(), d.data_ptr(),
+    tcall("mfnet_ce_loss_bwd", logits.numel() * 8 + target.numel() * 8, 0, logits.data_ptr(), target.data_ptr(), _p(weight), acc.data_ptr(), d.data_ptr(),
          float(gscale), B, C, HW, ignore_index, _stream(logits))
     return d
 
@@ -576,7 +601,7 @@ def ce_loss_bwd(logits, target, acc, weight=None, ignore_index=-100, gscale=1.0)
 def sgd_flat(p, g, buf, lr, momentum, wd, gscale=1.0):
     _chk(p, g, buf)
     assert p.is_contiguous() and g.is_contiguous() and p.numel() == g.numel()
-    call("mfnet_sgd_flat", p.data_ptr(), g.data_ptr(), _p(buf), p.numel(), float(lr), float(momentum), float(wd),
+    tcall("mfnet_sgd_flat", p.numel() * 4 * (4 if buf is None else 5) - (p.numel() * 4 if buf is None else 0), 0, p.data_ptr(), g.data_ptr(), _p(buf), p.numel(), float(lr), float(momentum), float(wd),
          float(gscale), _stream(p))
 
 
@@ -788,7 +813,7 @@ def colsum(x, G, P, want_sq=False):
     assert x.is_contiguous() and x.numel() == G * P * C
     s = zeros((2 if want_sq else 1, G, C), x.device)
     ws, tk = _colreduce_ws(G, P, C, x.device)
-    call("mfnet_colsum", x.data_ptr(), _dt(x), s[0].data_ptr(), s[1].data_ptr() if want_sq else None, G, P, C,
+    tcall("mfnet_colsum", x.numel() * x.element_size(), 0, x.data_ptr(), _dt(x), s[0].data_ptr(), s[1].data_ptr() if want_sq else None, G, P, C,
          ws.data_ptr(), tk.data_ptr(), _stream(x))
     return s[0], (s[1] if want_sq else None)
 
@@ -799,7 +824,7 @@ def coldot(a, b, G, P):
     assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel() == G * P * C
     out = zeros((G, C), a.device)
     ws, tk = _colreduce_ws(G, P, C, a.device)
-    call("mfnet_coldot", a.data_ptr(), _dt(a), b.data_ptr(), _dt(b), out.data_ptr(), G, P, C, ws.data_ptr(), tk.data_ptr(), _stream(a))
+    tcall("mfnet_coldot", a.numel() * (a.element_size() + b.element_size()), 0, a.data_ptr(), _dt(a), b.data_ptr(), _dt(b), out.data_ptr(), G, P, C, ws.data_ptr(), tk.data_ptr(), _stream(a))
     return out
 
 
@@ -861,7 +886,8 @@ def bn_forward(x, gamma, beta, run_mean, run_var, nbt, training, eps=1e-5, momen
              _p(nbt), C, n_stat, float(eps), float(momentum), 1, _stream(x))
     elif training and C <= 1024:
         s, sq = colsum(x, 1, rows, want_sq=True)
-        call("mfnet_bn_train_apply", x.data_ptr(), _dt(x), s.data_ptr(), sq.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), _p(run_mean),
+        tcall("mfnet_bn_train_apply", rows * C * (x.element_size() + y.element_size() + (y2.element_size() if y2 is not None else 0)), 0,
+              x.data_ptr(), _dt(x), s.data_ptr(), sq.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), _p(run_mean),
              _p(run_var), _p(nbt), float(eps), float(momentum), gamma.data_ptr(), beta.data_ptr(), act, _p(chan_scale), rows_per_image,
              y.data_ptr(), _dt(y), _p(y2), _dt(y2) if y2 is not None else 0, rows, C, _stream(x))
         return y, y2, st[0], st[1]
@@ -887,7 +913,8 @@ def bn_forward(x, gamma, beta, run_mean, run_var, nbt, training, eps=1e-5, momen
                  C, rows, float(eps), float(momentum), 0, _stream(x))
             if store is not None and not capturing:
                 store[key] = [st, (WEIGHTS_EPOCH[0], run_mean._version, run_var._version), run_mean, run_var, float(eps)]
-    call("mfnet_bn_apply", x.data_ptr(), _dt(x), st[0].data_ptr(), st[1].data_ptr(), gamma.data_ptr(), beta.data_ptr(), act,
+    tcall("mfnet_bn_apply", rows * C * (x.element_size() + y.element_size() + (y2.element_size() if y2 is not None else 0)), 0,
+          x.data_ptr(), _dt(x), st[0].data_ptr(), st[1].data_ptr(), gamma.data_ptr(), beta.data_ptr(), act,
          _p(chan_scale), rows_per_image, y.data_ptr(), _dt(y), _p(y2), _dt(y2) if y2 is not None else 0, rows, C, _stream(x))
     return y, y2, st[0], st[1]
 
@@ -899,7 +926,7 @@ def bn_backward(dy, x, mean, rstd, gamma, beta, training, act=ACT_NONE, chan_sca
     assert dy.is_contiguous() and x.is_contiguous() and dy.shape == x.shape
     sums = zeros((2, C), x.device)
     ws, tk = _colreduce_ws(1, rows, C, x.device)
-    call("mfnet_bn_bwd_reduce", dy.data_ptr(), _dt(dy), x.data_ptr(), _dt(x), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+    tcall("mfnet_bn_bwd_reduce", rows * C * (dy.element_size() + x.element_size()), 0, dy.data_ptr(), _dt(dy), x.data_ptr(), _dt(x), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
          beta.data_ptr(), act, _p(chan_scale), rows_per_image, sums[0].data_ptr(), sums[1].data_ptr(), rows, C,
          ws.data_ptr(), tk.data_ptr(), _stream(x))
     dx = torch.empty((rows, C), dtype=dx_dtype, device=x.device)
@@ -909,7 +936,7 @@ def bn_backward(dy, x, mean, rstd, gamma, beta, training, act=ACT_NONE, chan_sca
         # dgamma / dbeta stay this rank's sums - the gradient exchange adds the ranks
         (g,), n_tot = _sync_sums([sums.clone()], rows)
         use = g * (float(rows) / float(n_tot))
-    call("mfnet_bn_bwd_apply", dy.data_ptr(), _dt(dy), x.data_ptr(), _dt(x), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+    tcall("mfnet_bn_bwd_apply", rows * C * (dy.element_size() + x.element_size() + dx.element_size()), 0, dy.data_ptr(), _dt(dy), x.data_ptr(), _dt(x), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
          beta.data_ptr(), act, _p(chan_scale), rows_per_image, use[0].data_ptr(), use[1].data_ptr(), 1 if training else 0,
          dx.data_ptr(), _dt(dx), rows, C, _stream(x))
     return dx, sums[1], sums[0]
@@ -936,7 +963,7 @@ def dwconv_fwd(x, w, bias, B, H, W, k, ext):
     C = x.shape[-1]
     assert x.is_contiguous() and x.dtype == torch.float32 and w.is_contiguous() and w.numel() == C * k * k
     y = torch.empty_like(x)
-    call("mfnet_dwconv_fwd", x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), B, H, W, C, k, 1 if ext else 0, _stream(x))
+    tcall("mfnet_dwconv_fwd", x.numel() * 8, 2.0 * x.numel() * k * k, x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), B, H, W, C, k, 1 if ext else 0, _stream(x))
     return y
 
 
@@ -946,7 +973,7 @@ def dwconv_bwd(dy, x, w, B, H, W, k, ext, want_bias=False):
     C = x.shape[-1]
     assert dy.is_contiguous() and x.is_contiguous() and x.dtype == torch.float32
     dx = torch.empty_like(x)
-    call("mfnet_dwconv_bwd_data", dy.data_ptr(), _dt(dy), w.data_ptr(), dx.data_ptr(), B, H, W, C, k, 1 if ext else 0, _stream(x))
+    tcall("mfnet_dwconv_bwd_data", dy.numel() * dy.element_size() + x.numel() * 4, 2.0 * x.numel() * k * k, dy.data_ptr(), _dt(dy), w.data_ptr(), dx.data_ptr(), B, H, W, C, k, 1 if ext else 0, _stream(x))
     slots = 32                                           # copies of dw / db the workgroups spread their atomics over
     dw = zeros((slots,) + tuple(w.shape), x.device)
     db = zeros((slots, C), x.device) if want_bias else None
@@ -998,7 +1025,7 @@ def upfuse_fwd(x, skip, perm, w, eps, B, H, W, out_dtype=torch.bfloat16):
     C = x.shape[-1]
     assert x.is_contiguous() and x.dtype == torch.float32 and skip.is_contiguous() and skip.shape == (B * H * W, C)
     out = torch.empty((B * H * W, C), dtype=out_dtype, device=x.device)
-    call("mfnet_upfuse_fwd", x.data_ptr(), skip.data_ptr(), _dt(skip), perm, w.data_ptr(), float(eps), out.data_ptr(), _dt(out), B, H, W, C, _stream(x))
+    tcall("mfnet_upfuse_fwd", x.numel() * 4 + skip.numel() * skip.element_size() + out.numel() * out.element_size(), 0, x.data_ptr(), skip.data_ptr(), _dt(skip), perm, w.data_ptr(), float(eps), out.data_ptr(), _dt(out), B, H, W, C, _stream(x))
     return out
 
 
@@ -1011,7 +1038,7 @@ def upfuse_bwd(df, x, skip, perm, w, eps, B, H, W, dskip_dtype=torch.bfloat16):
     dskip = torch.empty(skip.shape, dtype=dskip_dtype, device=x.device)
     dw = zeros(2, x.device)
     sums = torch.empty(64, dtype=torch.float32, device=x.device)          # 32 slots x 2, zeroed by the entry point
-    call("mfnet_upfuse_bwd", df.data_ptr(), x.data_ptr(), skip.data_ptr(), _dt(skip), perm, w.data_ptr(), float(eps), dx.data_ptr(),
+    tcall("mfnet_upfuse_bwd", df.numel() * 4 + x.numel() * 8 + skip.numel() * skip.element_size() + dskip.numel() * dskip.element_size(), 0, df.data_ptr(), x.data_ptr(), skip.data_ptr(), _dt(skip), perm, w.data_ptr(), float(eps), dx.data_ptr(),
          dskip.data_ptr(), _dt(dskip), dw.data_ptr(), sums.data_ptr(), B, H, W, C, _stream(x))
     return dx, dskip, dw
 
@@ -1020,7 +1047,7 @@ def up_final_fwd(x, B, h, w, ncls, s):
     _chk(x)
     assert x.is_contiguous() and x.dtype == torch.float32
     out = torch.empty((B, ncls, h * s, w * s), dtype=torch.float32, device=x.device)
-    call("mfnet_up_final_fwd", x.data_ptr(), x.shape[-1], out.data_ptr(), B, h, w, ncls, s, _stream(x))
+    tcall("mfnet_up_final_fwd", B * h * w * ncls * 4 + out.numel() * 4, 0, x.data_ptr(), x.shape[-1], out.data_ptr(), B, h, w, ncls, s, _stream(x))
     return out
 
 
@@ -1028,7 +1055,7 @@ def up_final_bwd(dlogits, ldx, B, h, w, ncls, s):
     _chk(dlogits)
     assert dlogits.is_contiguous() and dlogits.dtype == torch.float32
     dx = torch.empty((B * h * w, ldx), dtype=torch.bfloat16, device=dlogits.device)
-    call("mfnet_up_final_bwd", dlogits.data_ptr(), dx.data_ptr(), ldx, B, h, w, ncls, s, _stream(dlogits))
+    tcall("mfnet_up_final_bwd", dlogits.numel() * 4 + B * h * w * ncls * 2, 0, dlogits.data_ptr(), dx.data_ptr(), ldx, B, h, w, ncls, s, _stream(dlogits))
     return dx
 
 
@@ -1184,6 +1211,16 @@ def prepare_tiles(rgb_u8, dsm, labels, codes, mean=(0.485, 0.456, 0.406), std=(0
     return ro, do, lo
 
 
+def jitter_tiles(rgb_u8, params):
+    """Brightness / contrast jitter in place on uint8 patches [n,3,S,S] (multiscale_dataset.py:250-265); params fp32 [n,2] on the
+    device = (brightness, contrast) per tile, brightness <= 0: tile untouched."""
+    _chk(rgb_u8, params)
+    assert rgb_u8.is_contiguous() and rgb_u8.dtype == torch.uint8 and rgb_u8.dim() == 4 and rgb_u8.shape[1] == 3 and rgb_u8.shape[2] == rgb_u8.shape[3]
+    assert params.is_contiguous() and params.dtype == torch.float32 and tuple(params.shape) == (rgb_u8.shape[0], 2)
+    tcall("mfnet_jitter_tiles", rgb_u8.numel() * 3, 0, rgb_u8.data_ptr(), params.data_ptr(), rgb_u8.shape[0], rgb_u8.shape[2], _stream(rgb_u8))
+    return rgb_u8
+
+
 def tile_prob_accumulate(psum, cnt, logits, coords4, cls):
     """psum / cnt: int64 [H, W] (psum in fixed point, probability * 2^40): integer atomics, order-independent."""
     _chk(psum, cnt, logits, coords4)
@@ -1298,6 +1335,7 @@ def gather(pairs, accumulate=False):
     ddt = pairs[0][0].dtype
     desc = (ctypes.c_int64 * (17 * len(pairs)))()
     k = 0
+    nbytes = 0
     for dst, src in pairs:
         red_n, red_stride, scale = 1, 0, 1.0
         if isinstance(src, SplitSum):
@@ -1317,4 +1355,5 @@ def gather(pairs, accumulate=False):
         desc[k + 14], desc[k + 15] = red_n, red_stride
         desc[k + 16] = struct.unpack("<I", struct.pack("<f", scale))[0]
         k += 17
-    call("mfnet_gather_segments", ctypes.cast(desc, ctypes.c_void_p), len(pairs), _DT[ddt], 1 if accumulate else 0, _stream(pairs[0][0]))
+        nbytes += dst.numel() * (4 * red_n + dst.element_size() * (2 if accumulate else 1))
+    tcall("mfnet_gather_segments", nbytes, 0, ctypes.cast(desc, ctypes.c_void_p), len(pairs), _DT[ddt], 1 if accumulate else 0, _stream(pairs[0][0]))

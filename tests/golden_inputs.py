@@ -52,3 +52,7 @@ def multiscale_inputs():
     dsm[32:64, 0:32] = 7.0                       # patch index 8 (row 1, col 0 of the 8x8 patch grid) is flat (:206)
     lab = ((detfill.uniform("msd/lab", (256, 256)) + 1) * 3).astype(np.int64).clip(0, 5)
     return S, rgb, dsm, lab
+
+
+# (flip / rot90 code, brightness, contrast) of the jitter goldens (tests/golden/jitter.npz); case i acts on patch i + 3 of the 8 x 8 grid
+JITTER_CASES = [(0, 1.2, 1.2), (5, 0.8, 0.8), (3, 1.2, 0.8), (12, 0.8, 1.2), (9, 1.013, 0.957), (0, 1.0, 1.0)]

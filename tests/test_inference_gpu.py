@@ -458,3 +458,41 @@ def test_device_input_pipeline_vs_reference_golden():
         assert np.abs(out[0][c].cpu().numpy() - g[f"msd{c}_rgb"]).max() < 2e-6, c
         assert np.abs(out[1][c].cpu().numpy() - g[f"msd{c}_dsm"]).max() < 1e-6, c
         assert np.array_equal(out[2][c].cpu().numpy(), g[f"msd{c}_lab"].astype(np.int64)), c
+
+
+def test_device_jitter_vs_reference_golden():
+    """mfnet_jitter_tiles / DeviceAugment(jitter=...) against the reference's own brightness / contrast branch
+    (multiscale_dataset.py:250-265; tests/golden/jitter.npz). The kernel sums the fp32 products exactly (in double), numpy adds
+    them pairwise in fp32: the channel means differ in their last bits, which moves a pixel that lands within ~1e-5 of an integer
+    by one grey level - so: never more than one level, on fewer than 0.1 % of the pixels (measured: printed), everything else
+    bit-equal; a tile with brightness 0 is left untouched; the input batch is not modified."""
+    from golden_inputs import JITTER_CASES, multiscale_inputs
+    from ssrs_amd import ops
+    from ssrs_amd.data import DeviceAugment
+    g = golden("jitter")
+    S, rgb, dsm, lab = multiscale_inputs()
+    n = len(JITTER_CASES)
+    sl = [divmod(i + 3, 8) for i in range(n)]
+    r = torch.from_numpy(np.stack([rgb[:, a * S:(a + 1) * S, b * S:(b + 1) * S] for a, b in sl] + [rgb[:, :S, :S]])).cuda()
+    d = torch.from_numpy(np.stack([dsm[a * S:(a + 1) * S, b * S:(b + 1) * S] for a, b in sl] + [dsm[:S, :S]])).cuda()
+    l = torch.from_numpy(np.stack([lab[a * S:(a + 1) * S, b * S:(b + 1) * S] for a, b in sl] + [lab[:S, :S]])).cuda()
+    codes = torch.tensor([c for c, _, _ in JITTER_CASES] + [0], dtype=torch.int32)
+    jit = torch.tensor([[b, c] for _, b, c in JITTER_CASES] + [[0.0, 0.0]], dtype=torch.float32)
+    keep = r.clone()
+    # the kernel alone on the un-flipped patches: compare with the golden un-flipped (the jitter commutes with the pixel permutation)
+    ju8 = ops.jitter_tiles(r.clone(), jit.cuda())
+    assert torch.equal(ju8[n], r[n])                                        # brightness 0: untouched
+    out = DeviceAugment()(r, d, l, codes, jitter=jit)
+    assert torch.equal(r, keep)
+    off = tot = 0
+    for i in range(n):
+        got = out[0][i].cpu().numpy()
+        want = g[f"jit{i}_rgb"]
+        lvl = np.abs(got - want) * 255.0 * np.array([0.229, 0.224, 0.225], np.float32)[:, None, None]      # difference in grey levels
+        assert lvl.max() < 1.0 + 1e-3, (i, lvl.max())
+        off += int((lvl > 1e-3).sum()); tot += lvl.size
+        assert np.abs(out[1][i].cpu().numpy() - g[f"jit{i}_dsm"]).max() < 1e-6, i
+        assert np.array_equal(out[2][i].cpu().numpy(), g[f"jit{i}_lab"].astype(np.int64)), i
+    print(f"\n[device jitter] {off} of {tot} pixels one grey level away from the reference")
+    assert off < 1e-3 * tot
+    assert (ju8[:n] != r[:n]).sum() > 1000

@@ -273,3 +273,24 @@ def test_state_dict_layout_matches_reference():
         # strict load of a checkpoint written in the reference's layout
         ck = {k: torch.zeros(shape, dtype=getattr(torch, dt.split(".")[1])) for k, (shape, dt) in want.items()}
         m.load_state_dict(ck, strict=True)
+
+
+def test_jitter_restatement_vs_reference():
+    """R.jitter_patch against _apply_augmentation's brightness / contrast branch (multiscale_dataset.py:250-265) run on the imported
+    reference with a scripted `random` (tests/golden/jitter.npz): the uint8 patch bit for bit, then the normalised patch."""
+    from golden_inputs import JITTER_CASES, multiscale_inputs
+    g = golden("jitter")
+    S, rgb, dsm, lab = multiscale_inputs()
+    changed = 0
+    for i, (code, bf, cf) in enumerate(JITTER_CASES):
+        pr, pc = divmod(i + 3, 8)
+        raw = rgb[:, pr * S:(pr + 1) * S, pc * S:(pc + 1) * S]
+        a, z, l = R.augment_patch(raw, dsm[pr * S:(pr + 1) * S, pc * S:(pc + 1) * S], lab[pr * S:(pr + 1) * S, pc * S:(pc + 1) * S],
+                                  code & 1, (code >> 1) & 1, (code >> 2) & 3)
+        j = R.jitter_patch(a, bf, cf)
+        assert j.dtype == np.uint8 and np.array_equal(j, g[f"jit{i}_u8"]), i
+        changed += int((j != a).sum())
+        an, zn = R.normalise_patch(j, z)
+        assert np.abs(an - g[f"jit{i}_rgb"]).max() < 1e-6 and np.abs(zn - g[f"jit{i}_dsm"]).max() < 1e-6, i
+        assert np.array_equal(l, g[f"jit{i}_lab"].astype(np.int64)), i
+    assert changed > 1000                        # the fixtures do exercise the branch

@@ -3,8 +3,8 @@
 set -e -o pipefail
 OTHER=$1; N=${2:-2}
 for i in $(seq $N); do
-  MFNET_HIP_LIB=$OTHER timeout -k 10 150 python bench.py --no-cpu --steps 60 > gpurun_out/ab_a.json
-  timeout -k 10 150 python bench.py --no-cpu --steps 60 > gpurun_out/ab_b.json
+  MFNET_HIP_LIB=$OTHER timeout -k 10 150 python bench.py --no-cpu --no-h2d --steps 60 > gpurun_out/ab_a.json
+  timeout -k 10 150 python bench.py --no-cpu --no-h2d --steps 60 > gpurun_out/ab_b.json
   python - <<'PY'
 import json
 for tag, f in (("other", "gpurun_out/ab_a.json"), ("tree ", "gpurun_out/ab_b.json")):

@@ -376,7 +376,48 @@ def case_prepost():
     save("prepost", **arrs)
 
 
-CASES = dict(state_dict=case_state_dict, prepost=case_prepost, blocks=case_blocks, encoder=case_encoder, model_tiny=case_model_tiny,
+def case_jitter():
+    """MultiScaleSegmentationDataset._apply_augmentation's brightness / contrast branch (multiscale_dataset.py:250-265) with a
+    scripted `random`: the jittered uint8 patch it returns and the normalised fp32 patch `__getitem__` makes of it. The skimage
+    rescale branch stays scripted off (skimage is absent here)."""
+    _stub("skimage.transform", resize=None)
+    sys.modules["skimage"].transform = sys.modules["skimage.transform"]
+    import multiscale_dataset as MS
+    DS = MS.MultiScaleSegmentationDataset
+    from golden_inputs import JITTER_CASES
+    S, rgb, dsm, lab = multiscale_inputs()
+
+    class Scripted:
+        def __init__(self, seq, k, uni):
+            self.seq, self.k, self.uni = list(seq), k, list(uni)
+        def random(self):
+            return self.seq.pop(0)
+        def randint(self, a, b):
+            return self.k
+        def uniform(self, a, b):
+            v = self.uni.pop(0)
+            assert a <= v <= b
+            return v
+    ns = types.SimpleNamespace(tile_ids=["t"], window_size=(S, S), stride_size=S, augment=True, mean=np.array([0.485, 0.456, 0.406]),
+                               std=np.array([0.229, 0.224, 0.225]), _load_tile_data=lambda tid: (rgb, dsm, lab))
+    ns._apply_augmentation = lambda a, b, c: DS._apply_augmentation(ns, a, b, c)
+    arrs = {}
+    for i, (code, bf, cf) in enumerate(JITTER_CASES):
+        hf, vf, k = code & 1, (code >> 1) & 1, (code >> 2) & 3
+        seq = [0.9 if hf else 0.1, 0.9 if vf else 0.1, 0.9 if k else 0.1, 0.9, 0.1]       # flips / rot as coded, jitter ON, rescale OFF
+        MS.random = Scripted(seq, k, [bf, cf])
+        patch = i + 3                                       # patch 3 .. 8 of the 8 x 8 grid
+        pr, pc = divmod(patch, 8)
+        raw = rgb[:, pr * S:(pr + 1) * S, pc * S:(pc + 1) * S]
+        out_u8, _, _ = DS._apply_augmentation(ns, raw, dsm[pr * S:(pr + 1) * S, pc * S:(pc + 1) * S], lab[pr * S:(pr + 1) * S, pc * S:(pc + 1) * S])
+        assert out_u8.dtype == np.uint8 and not MS.random.seq and not MS.random.uni
+        MS.random = Scripted(seq, k, [bf, cf])
+        r, d, l = DS.__getitem__(ns, patch)
+        arrs[f"jit{i}_u8"], arrs[f"jit{i}_rgb"], arrs[f"jit{i}_dsm"], arrs[f"jit{i}_lab"] = out_u8, r, d, l.to(torch.uint8)
+    save("jitter", **arrs)
+
+
+CASES = dict(state_dict=case_state_dict, prepost=case_prepost, jitter=case_jitter, blocks=case_blocks, encoder=case_encoder, model_tiny=case_model_tiny,
              model_vitb=case_model_vitb, sliding=case_sliding, metrics=case_metrics)
 
 if __name__ == "__main__":
