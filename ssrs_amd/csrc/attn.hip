@@ -233,6 +233,226 @@ __global__ __launch_bounds__(256, (NSG == 1 && HD <= 64) ? 4 : ((ROWT && HD <= 6
   }
 }
 
+// =============================================================================================== pair-resident forward
+// Small token grids (T <= 256 tokens, key rows of at most 16 keys: the 256-px tiles of the training step, 14 x 14 windows and the
+// 16 x 16 global blocks). The tiled kernel above gives every 64-query tile a workgroup of its own that stages the window's K / V
+// again (7 tiles per image-head in a windowed block, three of them with 4 - 28 queries) and waits at two barriers per 128-key
+// chunk: its waves issue instructions in 28 % of their cycles (profiles/r03_b_attn_pmc.json). Here ONE workgroup owns an
+// (image-modality, head) pair: K and V of all its tokens are staged once, by token, plus one row for the padded key (the qkv bias),
+// and after that single barrier each wave walks 16-query tiles on its own - a window's keys are found through the token map, so
+// windows share the one image.
+//   Key order: a window's keys are laid out 16 per key ROW (kw < KW real, the rest masked), so a 16-key accumulator tile is one key
+// row kh: the decomposed rel-pos bias of lane (query, fq) is hb[kh] + wb[kw = 4 fq + r] - per-query table entries that start the
+// accumulator in fp32. No indicator image and none of its MFMAs (half of the score MFMAs of the tiled kernel), no per-chunk
+// staging, no barrier in the key loop.
+#define ATP_WAVES 6
+#define ATP_THREADS (64 * ATP_WAVES)
+#define ATP_ROWS 257                    // 256 tokens + the padded key
+#define ATP_TB_LD 36
+__host__ __device__ inline int atp_tiles16(const AttnGeom& g) {
+  int n = 0;
+  for (int wi = 0; wi < g.nWh; ++wi)
+    for (int wj = 0; wj < g.nWw; ++wj) {
+      const int rh = g.ws > 0 ? (g.ws < g.Sh - wi * g.ws ? g.ws : g.Sh - wi * g.ws) : g.Sh;
+      const int rw = g.ws > 0 ? (g.ws < g.Sw - wj * g.ws ? g.ws : g.Sw - wj * g.ws) : g.Sw;
+      n += (rh * rw + 15) / 16;
+    }
+  return n;
+}
+__device__ __forceinline__ void atp_locate_tile(const AttnGeom& g, int t, int* wi, int* wj, int* q0) {
+  int i = 0, j = 0;
+  for (int w = 0; w + 1 < g.nWh * g.nWw; ++w) {
+    const int nt = (num_queries(g, i, j) + 15) >> 4;
+    if (t < nt) break;
+    t -= nt;
+    if (++j == g.nWw) { j = 0; ++i; }
+  }
+  *wi = i; *wj = j; *q0 = t * 16;
+}
+
+template <int HD>
+__global__ __launch_bounds__(ATP_THREADS, 3) void attn_fwd_pair_kernel(const AttnFwdParams p) {
+  typedef AttHd<HD> H;
+  static_assert(HD == 64, "pair-resident attention: head dim 64");
+  constexpr int KS = H::KS, UT = H::UT, ROWB = H::ROWB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const AttnGeom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int T = g.Sh * g.Sw;
+  const int gi = blockIdx.x / g.heads, head = blockIdx.x - gi * g.heads;
+  unsigned char* K_lds = smem;
+  unsigned char* V_lds = smem + ATP_ROWS * ROWB;
+  float* Tb = (float*)(smem + 2 * ATP_ROWS * ROWB) + (wave * 16 + fr) * ATP_TB_LD;      // this lane's query row of the wave's table block
+  const int64_t row_base = (int64_t)gi * T;
+  const int ld = 3 * g.D;
+  const bf16_t* qkv_img = p.qkv + row_base * ld;
+
+  // ---- stage K / V of every token once (16-B chunks, XOR-swizzled by row), and the padded key's row
+  {
+    constexpr int NLD = (256 * 8 + ATP_THREADS - 1) / ATP_THREADS;
+    u32x4_t kr[NLD], vr[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + i * ATP_THREADS, row = min(idx >> 3, T - 1), ch = idx & 7;
+      const bf16_t* src = qkv_img + (row * ld + g.D + head * HD + ch * 8);
+      kr[i] = *reinterpret_cast<const u32x4_t*>(src);
+      vr[i] = *reinterpret_cast<const u32x4_t*>(src + g.D);
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + i * ATP_THREADS, row = idx >> 3, ch = idx & 7;
+      if (row < T) {
+        *reinterpret_cast<u32x4_t*>(K_lds + row * ROWB + ((ch ^ kswz(row)) << 4)) = kr[i];
+        *reinterpret_cast<u32x4_t*>(V_lds + row * ROWB + ((ch ^ kswz(row)) << 4)) = vr[i];
+      }
+    }
+    if (tid < 8) {
+      const PaddedKV pad = att_padded_kv(p.qkv_bias, g.D, head, HD, tid);
+      *reinterpret_cast<u32x4_t*>(K_lds + 256 * ROWB + ((tid ^ kswz(256)) << 4)) = pad.k;
+      *reinterpret_cast<u32x4_t*>(V_lds + 256 * ROWB + ((tid ^ kswz(256)) << 4)) = pad.v;
+    }
+  }
+  __syncthreads();
+
+  const float cs = g.scale * 1.4426950408889634f, inv = 1.0f / g.scale;
+  const int ntile = atp_tiles16(g);
+  const int nkt = (g.KH + 3) >> 2;
+  for (int tile = wave; tile < ntile; tile += ATP_WAVES) {
+    int wi, wj, q0;
+    atp_locate_tile(g, tile, &wi, &wj, &q0);
+    const QueryPos qp = query_pos(g, wi, wj, q0 + fr);
+    bf16x8_t qf[KS];
+    att_load_row_frags<HD>(qkv_img + qp.tok * ld + head * HD, fq, qp.valid, qf);
+    const int oh = g.ws > 0 ? wi * g.ws : 0, ow = g.ws > 0 ? wj * g.ws : 0;
+    // LDS row of key (kh, kw) of this window: its token, the padded key's row, or (beyond the key grid: masked) any row
+    auto key_row = [&](int kh, int kw) -> int {
+      const int y = oh + kh, x = ow + kw;
+      return (kh < g.KH && kw < g.KW && y < g.Sh && x < g.Sw) ? y * g.Sw + x : 256;
+    };
+    // ---- T^T = tbl . Q^T, 32 table rows at a time through the wave's block buffer; each block hands over the entries this query
+    // uses: hb[kh] = T[q][(KH-1-kh) + qh] / scale, wb[r] = T[q][Lh + (KW-1-kw) + qw] / scale for kw = 4 fq + r (-inf: no such key)
+    float hb[16], wb[4];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      // pass 0: table rows [0, 32) hold every h row a query uses ((KH-1-kh) + qh <= 30); pass 1: rows [Lh, Lh + 32) every w row
+      const int b0 = pass ? g.Lh : 0;
+      bf16x8_t a[2][KS];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bf16_t* tp = p.tbl + (int64_t)min(b0 + 16 * i + fr, g.NT - 1) * H::HDP + 8 * fq;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a[i][ks] = *reinterpret_cast<const bf16x8_t*>(tp + 32 * ks);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], qf[ks], acc, 0, 0, 0);
+        *reinterpret_cast<float4*>(Tb + 16 * i + 4 * fq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      }
+      if (pass == 0) {
+#pragma unroll
+        for (int kh = 0; kh < 16; ++kh) {
+          const float v = Tb[max(g.KH - 1 - kh, 0) + qp.qh] * inv;
+          hb[kh] = kh < g.KH ? v : -INFINITY;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kw = 4 * fq + r;
+          const float v = Tb[max(g.KW - 1 - kw, 0) + qp.qw] * inv;
+          wb[r] = kw < g.KW ? v : -INFINITY;
+        }
+      }
+    }
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4_t o[UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) o[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      if (kt < nkt) {
+        // ---- S^T tiles: key row kh = 4 kt + t on the accumulator rows (kw = 4 fq + r), the query on the lane
+        f32x4_t s[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float hv = hb[4 * kt + t];
+          s[t] = (f32x4_t){wb[0] + hv, wb[1] + hv, wb[2] + hv, wb[3] + hv};
+          const int kr = key_row(4 * kt + t, fr);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(K_lds + kr * ROWB + (((fq + 4 * ks) ^ kswz(kr)) << 4));
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+          }
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) tmax = fmaxf(tmax, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);    // m_run = -inf on the first tile -> 0
+        const float mc = m_new * cs;
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(s[t][r], cs, -mc));
+            s[t][r] = e;
+            psum += e;
+          }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int u = 0; u < UT; ++u) { o[u][0] *= alpha; o[u][1] *= alpha; o[u][2] *= alpha; o[u][3] *= alpha; }
+        // ---- O^T += V^T . P^T (k-slot (fq, j) of k-step s2 <-> key row 4 kt + 2 s2 + (j >> 2), key column 4 fq + (j & 3)); V^T by
+        // transposing reads of 4 keys x 16 head dims (lane 4q+p of a 16-lane group addresses key column 4 fq + q)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          union { bf16x8_t v; unsigned int w[4]; } pf;
+          pf.w[0] = pack_bf16x2(s[2 * s2][0], s[2 * s2][1]);
+          pf.w[1] = pack_bf16x2(s[2 * s2][2], s[2 * s2][3]);
+          pf.w[2] = pack_bf16x2(s[2 * s2 + 1][0], s[2 * s2 + 1][1]);
+          pf.w[3] = pack_bf16x2(s[2 * s2 + 1][2], s[2 * s2 + 1][3]);
+          const int v0 = key_row(4 * kt + 2 * s2, 4 * fq + (fr >> 2)), v1 = key_row(4 * kt + 2 * s2 + 1, 4 * fq + (fr >> 2));
+#pragma unroll
+          for (int u = 0; u < UT; ++u) {
+            const int chn = 2 * u + ((fr >> 1) & 1), sub = (fr & 1) << 3;
+            union { bf16x8_t v; s16x4_t h[2]; } vf;
+            vf.h[0] = att_tr_read(V_lds + v0 * ROWB + ((chn ^ kswz(v0)) << 4) + sub);
+            vf.h[1] = att_tr_read(V_lds + v1 * ROWB + ((chn ^ kswz(v1)) << 4) + sub);
+            o[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[u], 0, 0, 0);
+          }
+        }
+      }
+    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (qp.valid) {
+      const float il = 1.f / l_run;
+      bf16_t* op = p.out + (row_base + qp.tok) * g.D + head * HD + 4 * fq;
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        u32x2_t w;
+        w.x = pack_bf16x2(o[u][0] * il, o[u][1] * il);
+        w.y = pack_bf16x2(o[u][2] * il, o[u][3] * il);
+        *reinterpret_cast<u32x2_t*>(op + 16 * u) = w;
+      }
+      if (fq == 0 && p.lse) p.lse[((int64_t)gi * g.heads + head) * T + qp.tok] = m_run * g.scale + __logf(l_run);
+    }
+  }
+}
+// the pair-resident kernels apply: head dim 64, at most 256 tokens, key rows of at most 16 keys (MFNET_ATTN_PAIR=0: off, for A / B runs)
+bool attn_pair_resident(const AttnGeom& g, int hd) {
+  static const bool on = !(getenv("MFNET_ATTN_PAIR") && getenv("MFNET_ATTN_PAIR")[0] == '0');
+  // windowed blocks only: global attention over 16 x 16 tokens measured 32 us against 30 for the tiled kernel (4 full tiles per
+  // pair, nothing to merge), the 14 x 14 windows of the same grid 40 against 45
+  return on && hd == 64 && g.ws > 0 && g.Sh * g.Sw <= 256 && g.KH <= 16 && g.KW <= 16;
+}
+
 int attn_fill_geom(AttnGeom* g, int64_t G, int64_t Sh, int64_t Sw, int64_t heads, int64_t hd, int64_t ws,
                    int64_t Lh, int64_t Lw, int64_t NT, float scale, const char* who) {
   MF_CHECK_ARG(hd == 64 || hd == 80, "%s: head dim %lld unsupported (64: ViT-B / ViT-L, 80: ViT-H)", who, (long long)hd);
@@ -292,6 +512,10 @@ extern "C" int mfnet_attn_fwd(const void* qkv, const float* qkv_bias, const void
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { mfnet_set_error("attn_fwd: hipGetDevice failed"); return MFNET_ERR_HIP; }
     std::lock_guard<std::mutex> lk(mu);
     if (!done[dev]) {
+      {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_pair_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { mfnet_set_error("attn_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MFNET_ERR_HIP; }
+      }
       const void* fns[8] = {(const void*)attn_fwd_kernel<1, 64, false>, (const void*)attn_fwd_kernel<2, 64, false>, (const void*)attn_fwd_kernel<4, 64, false>,
                             (const void*)attn_fwd_kernel<1, 80, false>, (const void*)attn_fwd_kernel<2, 80, false>, (const void*)attn_fwd_kernel<4, 80, false>,
                             (const void*)attn_fwd_kernel<4, 64, true>, (const void*)attn_fwd_kernel<4, 80, true>};
@@ -303,6 +527,12 @@ extern "C" int mfnet_attn_fwd(const void* qkv, const float* qkv_bias, const void
     }
   }
   MF_CHECK_ARG(p.g.KH + p.g.KW <= 128, "attn_fwd: key grid %dx%d too large (KH + KW <= 128)", p.g.KH, p.g.KW);
+  if (attn_pair_resident(p.g, (int)hd)) {
+    const size_t plds = 2 * ATP_ROWS * AttHd<64>::ROWB + ATP_WAVES * 16 * ATP_TB_LD * 4;
+    hipLaunchKernelGGL((attn_fwd_pair_kernel<64>), dim3((unsigned)(heads * G)), dim3(ATP_THREADS), plds, stream, p);
+    MF_LAUNCH_CHECK("attn_fwd(pair)");
+    return MFNET_OK;
+  }
   p.g.ntile = attn_query_tiles(p.g);
   const int64_t nwg = att_grid(p.g.ntile, heads * G);
   MF_CHECK_ARG(nwg < (1ll << 31), "attn_fwd: grid too large");

@@ -268,19 +268,20 @@ def _frh32(m, x, res, perm, B, H, W):
 
 
 def decoder32(dec, res1, res2, res3, res4, B, S, h, w, perms=(2, 1)):
-    """Decoder.forward (unetformer_mmsam.py:444-457), eval mode (Dropout2d is the identity)."""
-    if S % 2 or h != 16 * S or w != 16 * S:
-        raise NotImplementedError("the HIP decoder handles square pyramids with logits = 16x the encoder grid")
+    """Decoder.forward (unetformer_mmsam.py:444-457), eval mode (Dropout2d is the identity). S: the token grid (Sh, Sw)."""
+    Sh, Sw = (S, S) if isinstance(S, int) else (int(S[0]), int(S[1]))
+    if Sh % 2 or Sw % 2 or h != 16 * Sh or w != 16 * Sw:
+        raise NotImplementedError("the HIP decoder handles inputs whose height and width are multiples of 32")
     x = _bn(gemm32(res4, _w2(dec.pre_conv[0].weight)), dec.pre_conv[1])
-    x = _block32(dec.b4, x, B, S // 2, S // 2)
-    x = _block32(dec.b3, _fuse32(dec.p3, x, res3, 0, B, S, S), B, S, S)
-    x = _block32(dec.b2, _fuse32(dec.p2, x, res2, perms[1], B, 2 * S, 2 * S), B, 2 * S, 2 * S)
-    x = _frh32(dec.p1, x, res1, perms[0], B, 4 * S, 4 * S)
+    x = _block32(dec.b4, x, B, Sh // 2, Sw // 2)
+    x = _block32(dec.b3, _fuse32(dec.p3, x, res3, 0, B, Sh, Sw), B, Sh, Sw)
+    x = _block32(dec.b2, _fuse32(dec.p2, x, res2, perms[1], B, 2 * Sh, 2 * Sw), B, 2 * Sh, 2 * Sw)
+    x = _frh32(dec.p1, x, res1, perms[0], B, 4 * Sh, 4 * Sw)
     head = dec.segmentation_head
-    hb = _bn(conv3x3_32(x, head[0][0].weight, B, 4 * S, 4 * S), head[0][1], act=ACT_RELU6)
+    hb = _bn(conv3x3_32(x, head[0][0].weight, B, 4 * Sh, 4 * Sw), head[0][1], act=ACT_RELU6)
     wcls = _w2(head[2][0].weight)
     lg = gemm32(hb, wcls)
-    return ops.up_final_fwd(lg, B, 4 * S, 4 * S, wcls.shape[0], 4)
+    return ops.up_final_fwd(lg, B, 4 * Sh, 4 * Sw, wcls.shape[0], 4)
 
 
 @torch.no_grad()
@@ -292,4 +293,4 @@ def forward_fp32(model, x, y):
     B = x.shape[0]
     deep = encoder32(model.image_encoder, x, y)
     res1, res2, res3, res4 = fpn_fusion32(model, deep)
-    return decoder32(model.decoder, res1, res2, res3, res4, B, deep.shape[1], h, w)
+    return decoder32(model.decoder, res1, res2, res3, res4, B, (deep.shape[1], deep.shape[2]), h, w)

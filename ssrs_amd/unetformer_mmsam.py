@@ -251,26 +251,30 @@ class Decoder(nn.Module):
 
     def forward_rows(self, res1, res2, res3, res4, B, S, h, w, perms=(2, 1)):
         """res_i: bf16 channels-last rows of the 4S, 2S, S, S/2 pyramid levels (res1 / res2 in the
-        un-shuffled ConvTranspose order `perms`); returns logits (B, ncls, h, w) fp32."""
-        if S % 2 or h != 16 * S or w != 16 * S:
-            raise NotImplementedError("the HIP decoder handles square pyramids with logits = 16x the encoder grid")
+        un-shuffled ConvTranspose order `perms`); S = the encoder's token grid, an int (square) or (Sh, Sw); returns logits
+        (B, ncls, h, w) fp32. Any H x W whose token grid is even in both directions (H, W multiples of 32) is accepted, as the
+        reference's forward does (unetformer_mmsam.py:533-563); the logits are the 16x grid, so h = 16 Sh, w = 16 Sw."""
+        Sh, Sw = (S, S) if isinstance(S, int) else (int(S[0]), int(S[1]))
+        if Sh % 2 or Sw % 2 or h != 16 * Sh or w != 16 * Sw:
+            raise NotImplementedError("the HIP decoder handles inputs whose height and width are multiples of 32 (an even token grid, "
+                                      "logits = 16x the grid); got a %dx%d grid for %dx%d logits" % (Sh, Sw, h, w))
         tr = self.training
         x = D.ConvBN1x1Fn.apply(res4, self.pre_conv, tr, *D.convbn_params(self.pre_conv))
-        x = self.b4.forward_rows(x, (B, S // 2, S // 2))
-        x = self.b3.forward_rows(self.p3.forward_rows(x, res3, 0, (B, S, S)), (B, S, S))
-        x = self.b2.forward_rows(self.p2.forward_rows(x, res2, perms[1], (B, 2 * S, 2 * S)), (B, 2 * S, 2 * S))
-        x = self.p1.forward_rows(x, res1, perms[0], (B, 4 * S, 4 * S))
+        x = self.b4.forward_rows(x, (B, Sh // 2, Sw // 2))
+        x = self.b3.forward_rows(self.p3.forward_rows(x, res3, 0, (B, Sh, Sw)), (B, Sh, Sw))
+        x = self.b2.forward_rows(self.p2.forward_rows(x, res2, perms[1], (B, 2 * Sh, 2 * Sw)), (B, 2 * Sh, 2 * Sw))
+        x = self.p1.forward_rows(x, res1, perms[0], (B, 4 * Sh, 4 * Sw))
         drop = self.segmentation_head[1]
         mask = None
         if drop.training and drop.p > 0:
             keep = 1.0 - drop.p
             mask = torch.bernoulli(torch.full((B, x.shape[1]), keep, device=x.device)) / keep     # Dropout2d: per (image, channel)
-        return D.SegHeadFn.apply(x, self.segmentation_head, (B, 4 * S, 4 * S), 4, mask, tr, *D.seghead_params(self.segmentation_head))
+        return D.SegHeadFn.apply(x, self.segmentation_head, (B, 4 * Sh, 4 * Sw), 4, mask, tr, *D.seghead_params(self.segmentation_head))
 
     def forward(self, res1, res2, res3, res4, h, w):
-        B, _, S, _ = res3.shape
+        B, _, Sh, Sw = res3.shape
         r = [D.to_rows(t, torch.bfloat16) for t in (res1, res2, res3, res4)]
-        return self.forward_rows(r[0], r[1], r[2], r[3], B, S, h, w, perms=(0, 0))
+        return self.forward_rows(r[0], r[1], r[2], r[3], B, (Sh, Sw), h, w, perms=(0, 0))
 
 
 class UNetFormer(nn.Module):
@@ -325,6 +329,9 @@ class UNetFormer(nn.Module):
         self.decoder = Decoder(ec, decode_channels, dropout, window_size, num_classes)
 
     def forward(self, x, y, mode='Train'):
+        if x.shape[-2] % 32 or x.shape[-1] % 32:
+            raise NotImplementedError("the HIP path takes tiles whose height and width are multiples of 32 (an even token grid for the "
+                                      "2x2 max-pool level); got %dx%d" % (x.shape[-2], x.shape[-1]))
         if self.precision == "fp32":
             from .fp32_path import forward_fp32
             return forward_fp32(self, x, y)
@@ -332,7 +339,7 @@ class UNetFormer(nn.Module):
         B = x.shape[0]
         deep = self.image_encoder.forward_stacked(x, y)             # [2B, H/16, W/16, 256] channels-last
         res1, res2, res3, res4 = D.FpnFusionFn.apply(deep, self, self.training, *D.fpn_fusion_params(self))
-        return self.decoder.forward_rows(res1, res2, res3, res4, B, deep.shape[1], h, w)
+        return self.decoder.forward_rows(res1, res2, res3, res4, B, (deep.shape[1], deep.shape[2]), h, w)
 
 
 UNetFormer_MMSAM = UNetFormer

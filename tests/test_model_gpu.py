@@ -273,6 +273,51 @@ def test_tiny_model_train_step_vs_reference(mod):
     assert abs(losses[1] - float(g["loss1"])) < 5e-3 * float(g["loss1"])
 
 
+def test_non_square_tiles_vs_reference_and_oracle():
+    """`forward` takes any H x W whose token grid is even in both directions (the reference: unetformer_mmsam.py:533-563).
+    (1) a 192 x 256 tile (12 x 16 tokens: padded 14 x 14 windows, interpolated global tables, GLA maps reflect-padded along H)
+    against the REFERENCE's own logits (model_tiny_rect.npz), bf16 at 2e-2 and the fp32 path at 1e-4; (2) a 256 x 320 tile (16 x 20
+    tokens; its decoder maps need the reflect pad along W, which the reference's GlobalLocalAttention.pad cannot do - a 2-element
+    reflect pad of a 4-D map raises in torch) against the float64 oracle, whose pad handles both directions; (3) train steps on the
+    non-square tile through the graph-captured engine learn."""
+    from oracle import mfnet_ref as R
+    from ssrs_amd.trainer import TrainEngine
+    tag = "model_tiny_rect"
+    g = golden(tag)
+    m = _tiny_model("sam_lora")
+    fill = detfill.fill_state_dict(m.state_dict(), tag + "/")
+    m.load_state_dict(fill)
+    sd = {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in m.state_dict().items()}
+    m = m.cuda().eval()
+    rgb = torch.from_numpy(0.5 * (detfill.uniform(tag + "/rgb", (2, 3, 192, 256)) + 1.0)).float()
+    dsm = torch.from_numpy(0.5 * (detfill.uniform(tag + "/dsm", (2, 192, 256)) + 1.0)).float()
+    with torch.no_grad():
+        out = m(rgb.cuda(), dsm.cuda())
+        m.precision = "fp32"
+        out32 = m(rgb.cuda(), dsm.cuda())
+        m.precision = "bf16"
+    assert out.shape == (2, 6, 192, 256)
+    e, e32 = rel_err(out[:, :, ::4, ::4], g["eval_logits_s4"]), rel_err(out32[:, :, ::4, ::4], g["eval_logits_s4"])
+    agree32 = float((out32.argmax(1).cpu().numpy() == g["eval_argmax"]).mean())
+    print(f"\n[192x256 tile] bf16 logits {e:.2e}, fp32 logits {e32:.2e}, fp32 argmax agreement {100 * agree32:.4f} %")
+    assert e < BF16_TOL and e32 < 1e-4 and agree32 >= 0.999
+    cfg = R.vit_cfg("tiny", mod="sam_lora", dim=128, depth=2, heads=2, global_idx=(1,))
+    rgb2 = torch.from_numpy(0.5 * (detfill.uniform(tag + "/rgb2", (1, 3, 256, 320)) + 1.0)).float()
+    dsm2 = torch.from_numpy(0.5 * (detfill.uniform(tag + "/dsm2", (1, 256, 320)) + 1.0)).float()
+    with torch.no_grad():
+        ref2 = R.unetformer(sd, rgb2.double(), dsm2.double(), cfg, training=False)
+        got2 = m(rgb2.cuda(), dsm2.cuda())
+    assert rel_err(got2, ref2) < BF16_TOL
+    m.train()
+    m.decoder.segmentation_head[1].p = 0.0
+    tgt = torch.from_numpy(np.minimum((0.5 * (detfill.uniform(tag + "/tgt", (2, 192, 256)) + 1.0) * 6).astype(np.int64), 5)).cuda()
+    eng = TrainEngine(m, lr=0.01, momentum=0.9, weight_decay=5e-4, class_weight=torch.ones(6, device="cuda"), use_graph=True)
+    losses = [TrainEngine.read_metrics(eng.step(rgb.cuda(), dsm.cuda(), tgt))["loss"] for _ in range(6)]
+    assert all(np.isfinite(l) for l in losses) and losses[-1] < losses[0], losses
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 3, 240, 256, device="cuda"), torch.zeros(1, 240, 256, device="cuda"))      # 15 x 16 tokens: odd grid
+
+
 def test_vitb_eval_logits_vs_reference():
     """BASELINE config: ViT-B MMLoRA, 256x256 tile; logits 2e-2 relative, argmax >= 99.9 %."""
     from ssrs_amd.unetformer_mmsam import UNetFormer

@@ -165,6 +165,23 @@ def test_tiny_model_eval_and_train_steps(mod):
     run_oracle_train_steps(g, tag, mod, 6)
 
 
+def test_tiny_model_non_square_tile():
+    """The reference's forward takes any H x W (unetformer_mmsam.py:533-563): a 192 x 256 tile (12 x 16 tokens) through the imported
+    reference (model_tiny_rect.npz) against the oracle restatement."""
+    tag = "model_tiny_rect"
+    g = golden(tag)
+    m = _tiny_model("sam_lora")
+    sd = _dbl(detfill.fill_state_dict(m.state_dict(), tag + "/"))
+    cfg = R.vit_cfg("tiny", mod="sam_lora", dim=128, depth=2, heads=2, global_idx=(1,))
+    rgb = torch.from_numpy(0.5 * (detfill.uniform(tag + "/rgb", (2, 3, 192, 256)) + 1.0)).double()
+    dsm = torch.from_numpy(0.5 * (detfill.uniform(tag + "/dsm", (2, 192, 256)) + 1.0)).double()
+    with torch.no_grad():
+        out = R.unetformer(sd, rgb, dsm, cfg, training=False)
+    assert out.shape == (2, 6, 192, 256)
+    assert rel_err(out[:, :, ::4, ::4], g["eval_logits_s4"]) < 1e-9
+    assert (out.argmax(1).numpy() == g["eval_argmax"]).mean() > 0.9999
+
+
 def test_tiny_model_ignore_index_255():
     tag = "model_tiny_ignore255"
     run_oracle_train_steps(golden(tag), tag, "sam_lora", 2, ignore=255)

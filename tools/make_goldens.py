@@ -220,6 +220,17 @@ def case_model_tiny():
                     eval_chan_sum=out.double().sum((0, 2, 3)))
         arrs.update(_train_step_arrays(m, tag, 2, 6))
         save(tag, **arrs)
+    # a NON-SQUARE tile through the unmodified reference forward (unetformer_mmsam.py:533-563 takes any H x W): 192 x 256 pixels =
+    # a 12 x 16 token grid (padded 14 x 14 windows, interpolated global tables, GLA maps reflect-padded along H; the reference's GlobalLocalAttention.pad cannot pad W - a 2-element reflect pad of a 4-D map raises - so W stays a multiple of 256)
+    tag = "model_tiny_rect"
+    m = _build_model("sam_lora", "tiny")
+    m.load_state_dict(detfill.fill_state_dict(m.state_dict(), tag + "/"))
+    m = m.double().eval()
+    rgb = torch.from_numpy(0.5 * (detfill.uniform(tag + "/rgb", (2, 3, 192, 256)) + 1.0)).double()
+    dsm = torch.from_numpy(0.5 * (detfill.uniform(tag + "/dsm", (2, 192, 256)) + 1.0)).double()
+    with torch.no_grad():
+        out = m(rgb, dsm)
+    save(tag, eval_logits_s4=out[:, :, ::4, ::4], eval_argmax=out.argmax(1).to(torch.uint8), eval_chan_sum=out.double().sum((0, 2, 3)))
     tag = "model_tiny_ignore255"
     m = _build_model("sam_lora", "tiny", num_classes=2)
     m.load_state_dict(detfill.fill_state_dict(m.state_dict(), tag + "/"))
