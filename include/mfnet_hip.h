@@ -465,7 +465,6 @@ int mfnet_confusion(const unsigned char* pred, const int64_t* gt, int64_t* cm, i
 
 /* ---- fp32-accurate forward path (csrc/fp32.hip): the reference's arithmetic is fp32 throughout (unetformer_mmsam.py:533-563,
  * lora_block.py:169-196); these entry points reproduce its logits to 1e-4 relative where the bf16 MFMA path gives 2e-2.
- * Inference / evaluation forward only.
  *
  * gemm_f32: out[m,n] = act(alpha * sum_k A[m,k] W[n,k] + bias[n]) (+ residual[m or m % res_row_mod, n]) (+ out[m,n] if accumulate),
  * all fp32, on v_mfma_f32_16x16x4_f32 (a k-ordered fp32 fma chain) - what F.linear / 1x1 convs / im2col'ed 3x3 convs and the
@@ -487,6 +486,27 @@ int mfnet_im2col_patch_f32(const float* rgb, const float* dsm, int dsm_channels,
 int mfnet_im2col3x3_f32(const float* x, float* cols, int64_t G, int64_t H, int64_t W, int64_t C, hipStream_t stream);
 int mfnet_gla_attn_fwd_f32(const float* qkv, const float* table, float* out, int64_t B, int64_t H, int64_t W, int64_t heads,
                            int64_t hd, int64_t ws, float scale, hipStream_t stream);
+
+/* ---- fp32 training (the reference trains in fp32: trainer.py:146-159): the backward twins the fp32 path needs beyond the
+ * dtype-flagged kernels above. The forward + backward of `UNetFormer(precision="fp32")` in train mode runs the same module
+ * backward passes as the bf16 path with every contraction on mfnet_gemm_f32 (dgrad = dy.W, wgrad = dy^T.x on transposed copies).
+ *
+ * attn_f32_bwd: dqkv of mfnet_attn_f32 (lora_block.py:169-196 differentiated; rel-pos tables and the qkv bias are frozen,
+ * unetformer_mmsam.py:522-528): `out` = the forward's output, dout its gradient, dqkv [G*Sh*Sw, 3*heads*hd] fully written.
+ * workspace: mfnet_attn_f32_bwd_workspace_floats(G, Sh, Sw, heads, ws) floats (row max+log-sum, delta and the per-query
+ * bias rows, handed from the dq kernel to the dk / dv kernel).
+ * gla_attn_bwd_f32 / up_final_bwd_f32 / adapter_mix_bwd_f32: mfnet_gla_attn_bwd / mfnet_up_final_bwd / mfnet_adapter_mix_bwd
+ * with fp32 qkv / dqkv, fp32 dx and fp32 dada. */
+int64_t mfnet_attn_f32_bwd_workspace_floats(int64_t G, int64_t Sh, int64_t Sw, int64_t heads, int64_t ws);
+int mfnet_attn_f32_bwd(const float* qkv, const float* qkv_bias, const float* th, const float* tw, const float* out, const float* dout,
+                       float* dqkv, int64_t G, int64_t Sh, int64_t Sw, int64_t heads, int64_t hd, int64_t ws, float scale,
+                       float* workspace, int64_t workspace_floats, hipStream_t stream);
+int mfnet_gla_attn_bwd_f32(const float* qkv, const float* table, const float* dout, float* dqkv, float* dtable, int64_t B, int64_t H,
+                           int64_t W, int64_t heads, int64_t hd, int64_t ws, float scale, hipStream_t stream);
+int mfnet_up_final_bwd_f32(const float* dlogits, float* dx, int64_t ldx, int64_t B, int64_t h, int64_t w, int64_t ncls, int64_t s,
+                           hipStream_t stream);
+int mfnet_adapter_mix_bwd_f32(const float* dh, const float* ada, const float* wx, const float* wy, float* dada, float* dw, int64_t M,
+                              int64_t D, hipStream_t stream);
 
 #ifdef __cplusplus
 }

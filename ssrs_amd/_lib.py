@@ -123,6 +123,11 @@ _SIGS = {
     "mfnet_im2col_patch_f32": [P, P, I, P, I64, I64, I64, I64, P],
     "mfnet_im2col3x3_f32": [P, P, I64, I64, I64, I64, P],
     "mfnet_gla_attn_fwd_f32": [P, P, P, I64, I64, I64, I64, I64, I64, F, P],
+    # ---- fp32 training: backward twins with fp32 operands / results
+    "mfnet_attn_f32_bwd": [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, F, P, I64, P],
+    "mfnet_gla_attn_bwd_f32": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, F, P],
+    "mfnet_up_final_bwd_f32": [P, P, I64, I64, I64, I64, I64, I64, P],
+    "mfnet_adapter_mix_bwd_f32": [P, P, P, P, P, P, I64, I64, P],
 }
 
 
@@ -148,6 +153,8 @@ def lib():
         L.mfnet_gemm_tn_splits.argtypes = [c_int64, c_int64, c_int64]
         L.mfnet_attn_bwd_workspace_floats.restype = c_int64
         L.mfnet_attn_bwd_workspace_floats.argtypes = [c_int64, c_int64, c_int64, c_int64, c_int64]
+        L.mfnet_attn_f32_bwd_workspace_floats.restype = c_int64
+        L.mfnet_attn_f32_bwd_workspace_floats.argtypes = [c_int64, c_int64, c_int64, c_int64, c_int64]
         for name, sig in _SIGS.items():
             fn = getattr(L, name, None)
             if fn is None:
@@ -160,7 +167,7 @@ def lib():
 
 def exported_symbols():
     return ["mfnet_version", "mfnet_last_error", "mfnet_skinny_tn_workspace_floats", "mfnet_gemm_tn_splits", "mfnet_colreduce_workspace_floats",
-            "mfnet_attn_bwd_workspace_floats", "mfnet_lora_side_splits"] + list(_SIGS)
+            "mfnet_attn_bwd_workspace_floats", "mfnet_lora_side_splits", "mfnet_attn_f32_bwd_workspace_floats"] + list(_SIGS)
 
 
 def call(name: str, *args):

@@ -82,6 +82,8 @@ class ParamBank:
 def derived(key, shape, dtype, fill: Callable[[torch.Tensor], List[Pair]], device=None) -> torch.Tensor:
     """Tensor of `shape` whose content is described by `fill(t) -> [(view of t, fp32 source view)]`; parts of
     t no pair covers stay zero. `key` must identify the sources (use their data_ptr()s) and the recipe."""
+    if ops.FP32 and dtype == torch.bfloat16:         # fp32 training: the GEMM image of a weight is the fp32 weight in the same layout
+        dtype, key = torch.float32, ("fp32",) + tuple(key)
     bank = ParamBank.active
     if bank is not None:
         hit = bank.entries.get(key)

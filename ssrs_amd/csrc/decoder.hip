@@ -1035,8 +1035,18 @@ __device__ __forceinline__ GlaRow gla_row(const float* v) {
 // One workgroup = one (window, head); its four waves split the 64 keys (pass 1) / the 64 queries (pass 2) and meet in LDS.
 // (One wave per (window, head) executed ~10 k dependent wave64 VALU instructions back to back: 45-120 us per launch whatever
 // the map size.)
-__global__ __launch_bounds__(256) void gla_attn_bwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ table,
-                                                           const float* __restrict__ dout, bf16_t* __restrict__ dqkv,
+__device__ __forceinline__ void gla_st8(bf16_t* p, const float* r) {
+  u32x4_t w;
+  w.x = pack_bf16x2(r[0], r[1]); w.y = pack_bf16x2(r[2], r[3]); w.z = pack_bf16x2(r[4], r[5]); w.w = pack_bf16x2(r[6], r[7]);
+  *reinterpret_cast<u32x4_t*>(p) = w;
+}
+__device__ __forceinline__ void gla_st8(float* p, const float* r) {          // fp32 training path
+  reinterpret_cast<float4*>(p)[0] = make_float4(r[0], r[1], r[2], r[3]);
+  reinterpret_cast<float4*>(p)[1] = make_float4(r[4], r[5], r[6], r[7]);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gla_attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ table,
+                                                           const float* __restrict__ dout, T* __restrict__ dqkv,
                                                            float* __restrict__ dtable, const GlaParams p, int nwin) {
   __shared__ GlaRow ql[64], kl[64], vl[64], dol[64];
   __shared__ float pm[4][64], pl[4][64], pd[4][64];             // per-wave partial max / sum / delta sum of each query
@@ -1120,9 +1130,7 @@ __global__ __launch_bounds__(256) void gla_attn_bwd_kernel(const bf16_t* __restr
     if (wv == 0) {
 #pragma unroll
       for (int d = 0; d < 8; ++d) dq[d] = (part[0][lane][d] + part[1][lane][d]) + (part[2][lane][d] + part[3][lane][d]);
-      u32x4_t w;
-      w.x = pack_bf16x2(dq[0], dq[1]); w.y = pack_bf16x2(dq[2], dq[3]); w.z = pack_bf16x2(dq[4], dq[5]); w.w = pack_bf16x2(dq[6], dq[7]);
-      *reinterpret_cast<u32x4_t*>(dqkv + row * Cq + head * GLA_HD) = w;
+      gla_st8(dqkv + row * Cq + head * GLA_HD, dq);
     }
     __syncthreads();                      // ml / ll / dl visible, part[] free again
     // ---- pass 2: this lane's key / value against this wave's 16 queries
@@ -1152,9 +1160,7 @@ __global__ __launch_bounds__(256) void gla_attn_bwd_kernel(const bf16_t* __restr
       float r[8];
 #pragma unroll
       for (int d = 0; d < 8; ++d) r[d] = (part[0][lane][8 * wv + d] + part[1][lane][8 * wv + d]) + (part[2][lane][8 * wv + d] + part[3][lane][8 * wv + d]);
-      u32x4_t w;
-      w.x = pack_bf16x2(r[0], r[1]); w.y = pack_bf16x2(r[2], r[3]); w.z = pack_bf16x2(r[4], r[5]); w.w = pack_bf16x2(r[6], r[7]);
-      *reinterpret_cast<u32x4_t*>(dqkv + row * Cq + ((1 + wv) * p.heads + head) * GLA_HD) = w;
+      gla_st8(dqkv + row * Cq + ((1 + wv) * p.heads + head) * GLA_HD, r);
     }
   }
   __syncthreads();
@@ -1198,9 +1204,21 @@ extern "C" int mfnet_gla_attn_bwd(const void* qkv, const float* table, const flo
   if (rc) return rc;
   const int64_t nwin = B * (H / GLA_WS) * (W / GLA_WS);
   const unsigned gx = (unsigned)(nwin < 512 ? nwin : 512);
-  hipLaunchKernelGGL(gla_attn_bwd_kernel, dim3(gx, (unsigned)heads), dim3(256), 0, stream, (const bf16_t*)qkv, table, dout,
+  hipLaunchKernelGGL(gla_attn_bwd_kernel<bf16_t>, dim3(gx, (unsigned)heads), dim3(256), 0, stream, (const bf16_t*)qkv, table, dout,
                      (bf16_t*)dqkv, dtable, p, (int)nwin);
   MF_LAUNCH_CHECK("gla_attn_bwd");
+  return MFNET_OK;
+}
+extern "C" int mfnet_gla_attn_bwd_f32(const float* qkv, const float* table, const float* dout, float* dqkv, float* dtable, int64_t B, int64_t H,
+                                      int64_t W, int64_t heads, int64_t hd, int64_t ws, float scale, hipStream_t stream) {
+  MF_CHECK_ARG(qkv && table && dout && dqkv && dtable, "gla_attn_bwd_f32: null pointer");
+  GlaParams p;
+  int rc = gla_check(&p, B, H, W, heads, hd, ws, scale, "gla_attn_bwd_f32");
+  if (rc) return rc;
+  const int64_t nwin = B * (H / GLA_WS) * (W / GLA_WS);
+  const unsigned gx = (unsigned)(nwin < 512 ? nwin : 512);
+  hipLaunchKernelGGL(gla_attn_bwd_kernel<float>, dim3(gx, (unsigned)heads), dim3(256), 0, stream, qkv, table, dout, dqkv, dtable, p, (int)nwin);
+  MF_LAUNCH_CHECK("gla_attn_bwd_f32");
   return MFNET_OK;
 }
 
@@ -1483,7 +1501,10 @@ __global__ __launch_bounds__(256) void up_final_fwd4_kernel(const float* __restr
 #define UPF_MAX_CLS 16
 // One thread per (image, class, low-resolution pixel), x fastest: neighbouring lanes read neighbouring windows of one class plane.
 // (One thread per pixel looping over the classes: 65 k threads of 600 loads each, 58 us.) Same sum order per element.
-__global__ __launch_bounds__(256) void up_final_bwd_cls_kernel(const float* __restrict__ dl, bf16_t* __restrict__ dx, int ldx, int B, int h, int wd, int ncls, int s) {
+__device__ __forceinline__ void upf_store(bf16_t* o, float v) { *o = f32_to_bf16(v); }
+__device__ __forceinline__ void upf_store(float* o, float v) { *o = v; }
+template <typename TO>
+__global__ __launch_bounds__(256) void up_final_bwd_cls_kernel(const float* __restrict__ dl, TO* __restrict__ dx, int ldx, int B, int h, int wd, int ncls, int s) {
   const int H = h * s, W = wd * s;
   const float inv = 1.f / (float)s;
   const int64_t total = (int64_t)B * ncls * h * wd;
@@ -1509,10 +1530,10 @@ __global__ __launch_bounds__(256) void up_final_bwd_cls_kernel(const float* __re
         acc = fmaf(wy[ky] * wx[kx], p[kx], acc);
       }
     }
-    bf16_t* o = dx + ((b * h + y) * (int64_t)wd + x) * ldx;
-    o[c] = f32_to_bf16(acc);
+    TO* o = dx + ((b * h + y) * (int64_t)wd + x) * ldx;
+    upf_store(o + c, acc);
     if (c == 0)
-      for (int z = ncls; z < ldx; ++z) o[z] = (bf16_t)0;
+      for (int z = ncls; z < ldx; ++z) upf_store(o + z, 0.f);
   }
 }
 extern "C" int mfnet_up_final_fwd(const float* x, int64_t ldx, float* logits, int64_t B, int64_t h, int64_t w, int64_t ncls, int64_t s, hipStream_t stream) {
@@ -1524,8 +1545,14 @@ extern "C" int mfnet_up_final_fwd(const float* x, int64_t ldx, float* logits, in
 }
 extern "C" int mfnet_up_final_bwd(const float* dlogits, void* dx, int64_t ldx, int64_t B, int64_t h, int64_t w, int64_t ncls, int64_t s, hipStream_t stream) {
   MF_CHECK_ARG(dlogits && dx && ncls > 0 && ncls <= ldx && ncls <= UPF_MAX_CLS && s >= 1 && s <= UPF_MAX_S, "up_final_bwd: bad args (classes <= 16, scale <= 8)");
-  hipLaunchKernelGGL(up_final_bwd_cls_kernel, dim3(grid_for(B * ncls * h * w)), dim3(256), 0, stream, dlogits, (bf16_t*)dx, (int)ldx, (int)B, (int)h, (int)w, (int)ncls, (int)s);
+  hipLaunchKernelGGL(up_final_bwd_cls_kernel<bf16_t>, dim3(grid_for(B * ncls * h * w)), dim3(256), 0, stream, dlogits, (bf16_t*)dx, (int)ldx, (int)B, (int)h, (int)w, (int)ncls, (int)s);
   MF_LAUNCH_CHECK("up_final_bwd");
+  return MFNET_OK;
+}
+extern "C" int mfnet_up_final_bwd_f32(const float* dlogits, float* dx, int64_t ldx, int64_t B, int64_t h, int64_t w, int64_t ncls, int64_t s, hipStream_t stream) {
+  MF_CHECK_ARG(dlogits && dx && ncls > 0 && ncls <= ldx && ncls <= UPF_MAX_CLS && s >= 1 && s <= UPF_MAX_S, "up_final_bwd_f32: bad args (classes <= 16, scale <= 8)");
+  hipLaunchKernelGGL(up_final_bwd_cls_kernel<float>, dim3(grid_for(B * ncls * h * w)), dim3(256), 0, stream, dlogits, dx, (int)ldx, (int)B, (int)h, (int)w, (int)ncls, (int)s);
+  MF_LAUNCH_CHECK("up_final_bwd_f32");
   return MFNET_OK;
 }
 

@@ -1,10 +1,11 @@
 // fp32-accurate forward path of MFNet (north star: "logits within 1e-4 relative for the fp32 path"; the reference computes
-// everything in fp32: unetformer_mmsam.py:533-563, lora_block.py:169-196). Eval / inference forward only.
+// everything in fp32: unetformer_mmsam.py:533-563, lora_block.py:169-196), and the contractions of fp32 training.
 //
 //   gemm_f32       out = act(alpha * A.W^T + bias) (+ residual) (+ out): fp32 operands on v_mfma_f32_16x16x4_f32, whose result is
 //                  a k-ordered fp32 fma chain (one rounding per product) - the arithmetic F.linear / 1x1 / im2col'ed convs have
 //   attn_f32       SAM ViT attention (windowed with zero-padded windows, or global) with the decomposed relative-position
 //                  bias, fp32 throughout: one lane = one query, keys / values streamed through LDS, online softmax per key tile
+//   attn_f32_bwd   its backward (dqkv), for fp32 training
 //   im2col*_f32    fp32 twins of the patch / 3x3 gathers
 // GLA's 8x8-window attention already computes in fp32; its fp32-input twin lives next to it in decoder.hip.
 #include "common.h"
@@ -242,6 +243,250 @@ extern "C" int mfnet_attn_f32(const float* qkv, const float* qkv_bias, const flo
   else if (hd == 80) hipLaunchKernelGGL(attn_f32_kernel<80>, grid, block, 0, stream, p);
   else hipLaunchKernelGGL(attn_f32_kernel<32>, grid, block, 0, stream, p);
   MF_LAUNCH_CHECK("attn_f32");
+  return MFNET_OK;
+}
+
+// =============================================================================== SAM ViT attention backward, fp32
+// (fp32 training: the reference trains in fp32, trainer.py:146-159.) Same geometry as attn_f32 above, rel-pos tables and the qkv bias
+// frozen (MFNet trains only the PEFT tensors: unetformer_mmsam.py:522-528), so the gradient is dqkv alone.
+//   dq kernel  (lane = query): sweep 1 over the window's keys -> row max / sum; sweep 2 -> p, dp = dO.v, ds = p (dp - delta),
+//              dq += ds (scale k + Th[.] + Tw[.]); leaves lse, delta and the query's bias rows (q.Th[*], q.Tw[*]) in the workspace
+//   dkv kernel (lane = key): the window's queries streamed through LDS 32 at a time; dk += scale ds q, dv += p dO
+// Padded window positions have no row in memory: their keys enter the softmax (forward), their gradients are dropped.
+struct AttnF32BwdParams {
+  const float* qkv; const float* qkv_bias; const float* th; const float* tw; const float* out; const float* dout; float* dqkv;
+  float* lse; float* delta; float* wbh; float* wbw;          // workspace: [slots], [slots], [slots][kh], [slots][kw]
+  int G, Sh, Sw, heads, kh, kw, nwh, nww, nkp; float scale;
+};
+template <int HD>
+__global__ __launch_bounds__(64) void attn_f32_bwd_dq_kernel(const AttnF32BwdParams p) {
+  __shared__ float kt[64][HD], vt[64][HD];
+  __shared__ float bh[64][AF_KMAX + 1], bw[64][AF_KMAX + 1];
+  const int lane = threadIdx.x;
+  const int head = blockIdx.x % p.heads;
+  const int win = blockIdx.x / p.heads;
+  const int g = win / (p.nwh * p.nww), wy = (win / p.nww) % p.nwh, wx = win % p.nww;
+  const int nk = p.kh * p.kw;
+  const int t = blockIdx.y * 64 + lane;
+  const int ty = t / p.kw, tx = t % p.kw;
+  const int qy = wy * p.kh + ty, qx = wx * p.kw + tx;
+  const bool live = t < nk && qy < p.Sh && qx < p.Sw;
+  const int64_t C3 = 3ll * p.heads * HD, C1 = (int64_t)p.heads * HD;
+  const int64_t slot = (int64_t)blockIdx.x * p.nkp + t;
+  float q[HD], dO[HD], dq[HD];
+  float delta = 0.f;
+#pragma unroll
+  for (int d = 0; d < HD; ++d) { q[d] = 0.f; dO[d] = 0.f; dq[d] = 0.f; }
+  if (live) {
+    const int64_t row = ((int64_t)g * p.Sh + qy) * p.Sw + qx;
+    const float* qp = p.qkv + row * C3 + head * HD;
+    const float* op = p.out + row * C1 + head * HD;
+    const float* dp = p.dout + row * C1 + head * HD;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(qp + d);
+      const float4 o = *reinterpret_cast<const float4*>(op + d);
+      const float4 e = *reinterpret_cast<const float4*>(dp + d);
+      q[d] = v.x; q[d + 1] = v.y; q[d + 2] = v.z; q[d + 3] = v.w;
+      dO[d] = e.x; dO[d + 1] = e.y; dO[d + 2] = e.z; dO[d + 3] = e.w;
+      delta = fmaf(o.x, e.x, fmaf(o.y, e.y, fmaf(o.z, e.z, fmaf(o.w, e.w, delta))));
+    }
+    for (int j = 0; j < p.kh; ++j) {
+      const float* r = p.th + (int64_t)(ty - j + p.kh - 1) * HD;
+      float a = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) a = fmaf(q[d], r[d], a);
+      bh[lane][j] = a;
+      p.wbh[slot * p.kh + j] = a;
+    }
+    for (int j = 0; j < p.kw; ++j) {
+      const float* r = p.tw + (int64_t)(tx - j + p.kw - 1) * HD;
+      float a = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) a = fmaf(q[d], r[d], a);
+      bw[lane][j] = a;
+      p.wbw[slot * p.kw + j] = a;
+    }
+  }
+  float mx = -FLT_MAX, l = 0.f, inv = 0.f;
+  constexpr int V4 = HD / 4;
+  for (int sweep = 0; sweep < 2; ++sweep) {
+    for (int j0 = 0; j0 < nk; j0 += 64) {
+      __syncthreads();
+      for (int i = lane; i < 64 * V4; i += 64) {
+        const int kj = i / V4, part = (i % V4) * 4;
+        const int j = j0 + kj;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+        if (j < nk) {
+          const int ky = wy * p.kh + j / p.kw, kx = wx * p.kw + j % p.kw;
+          const float* base = (ky < p.Sh && kx < p.Sw) ? p.qkv + (((int64_t)g * p.Sh + ky) * p.Sw + kx) * C3 + head * HD + part
+                                                       : p.qkv_bias + head * HD + part;
+          kv = *reinterpret_cast<const float4*>(base + C1);
+          vv = *reinterpret_cast<const float4*>(base + 2 * C1);
+        }
+        *reinterpret_cast<float4*>(&kt[kj][part]) = kv;
+        *reinterpret_cast<float4*>(&vt[kj][part]) = vv;
+      }
+      __syncthreads();
+      if (!live) continue;
+      const int nj = min(64, nk - j0);
+      for (int j = 0; j < nj; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) a = fmaf(q[d], kt[j][d], a);
+        const int jg = j0 + j, jy = jg / p.kw, jx = jg % p.kw;
+        a = a * p.scale + bh[lane][jy] + bw[lane][jx];
+        if (sweep == 0) {
+          const float nm = fmaxf(mx, a);
+          l = l * expf(mx - nm) + expf(a - nm);
+          mx = nm;
+        } else {
+          const float pr = expf(a - mx) * inv;
+          float dpv = 0.f;
+#pragma unroll
+          for (int d = 0; d < HD; ++d) dpv = fmaf(dO[d], vt[j][d], dpv);
+          const float ds = pr * (dpv - delta);
+          const float* rh = p.th + (int64_t)(ty - jy + p.kh - 1) * HD;
+          const float* rw = p.tw + (int64_t)(tx - jx + p.kw - 1) * HD;
+          const float dss = ds * p.scale;
+#pragma unroll
+          for (int d = 0; d < HD; ++d) dq[d] = fmaf(dss, kt[j][d], fmaf(ds, rh[d] + rw[d], dq[d]));
+        }
+      }
+    }
+    if (sweep == 0) inv = live ? 1.f / l : 0.f;
+  }
+  if (!live) return;
+  p.lse[slot] = mx + logf(l);
+  p.delta[slot] = delta;
+  float* o = p.dqkv + (((int64_t)g * p.Sh + qy) * p.Sw + qx) * C3 + head * HD;
+#pragma unroll
+  for (int d = 0; d < HD; d += 4) *reinterpret_cast<float4*>(o + d) = make_float4(dq[d], dq[d + 1], dq[d + 2], dq[d + 3]);
+}
+template <int HD>
+__global__ __launch_bounds__(64) void attn_f32_bwd_dkv_kernel(const AttnF32BwdParams p) {
+  __shared__ float ql[32][HD], dl[32][HD];
+  __shared__ float bh[32][AF_KMAX + 1], bw[32][AF_KMAX + 1];
+  __shared__ float lsel[32], dell[32];
+  __shared__ int livel[32];
+  const int lane = threadIdx.x;
+  const int head = blockIdx.x % p.heads;
+  const int win = blockIdx.x / p.heads;
+  const int g = win / (p.nwh * p.nww), wy = (win / p.nww) % p.nwh, wx = win % p.nww;
+  const int nk = p.kh * p.kw;
+  const int t = blockIdx.y * 64 + lane;
+  const int ty = t / p.kw, tx = t % p.kw;
+  const int ky = wy * p.kh + ty, kx = wx * p.kw + tx;
+  const bool live = t < nk && ky < p.Sh && kx < p.Sw;
+  const int64_t C3 = 3ll * p.heads * HD, C1 = (int64_t)p.heads * HD;
+  float k[HD], v[HD], dk[HD], dv[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) { k[d] = 0.f; v[d] = 0.f; dk[d] = 0.f; dv[d] = 0.f; }
+  const int64_t krow = ((int64_t)g * p.Sh + ky) * p.Sw + kx;
+  if (live) {
+    const float* base = p.qkv + krow * C3 + head * HD;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(base + C1 + d), b = *reinterpret_cast<const float4*>(base + 2 * C1 + d);
+      k[d] = a.x; k[d + 1] = a.y; k[d + 2] = a.z; k[d + 3] = a.w;
+      v[d] = b.x; v[d + 1] = b.y; v[d + 2] = b.z; v[d + 3] = b.w;
+    }
+  }
+  constexpr int V4 = HD / 4;
+  for (int i0 = 0; i0 < nk; i0 += 32) {
+    __syncthreads();
+    for (int i = lane; i < 32 * V4; i += 64) {
+      const int qi = i / V4, part = (i % V4) * 4;
+      const int tq = i0 + qi;
+      const int qy = wy * p.kh + tq / p.kw, qx = wx * p.kw + tq % p.kw;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+      if (tq < nk && qy < p.Sh && qx < p.Sw) {
+        const int64_t row = ((int64_t)g * p.Sh + qy) * p.Sw + qx;
+        a = *reinterpret_cast<const float4*>(p.qkv + row * C3 + head * HD + part);
+        b = *reinterpret_cast<const float4*>(p.dout + row * C1 + head * HD + part);
+      }
+      *reinterpret_cast<float4*>(&ql[qi][part]) = a;
+      *reinterpret_cast<float4*>(&dl[qi][part]) = b;
+    }
+    if (lane < 32) {
+      const int tq = i0 + lane;
+      const int qy = wy * p.kh + tq / p.kw, qx = wx * p.kw + tq % p.kw;
+      const bool lq = tq < nk && qy < p.Sh && qx < p.Sw;
+      const int64_t slot = (int64_t)blockIdx.x * p.nkp + tq;
+      livel[lane] = lq ? 1 : 0;
+      lsel[lane] = lq ? p.lse[slot] : 0.f;
+      dell[lane] = lq ? p.delta[slot] : 0.f;
+    }
+    for (int i = lane; i < 32 * (p.kh + p.kw); i += 64) {
+      const int qi = i / (p.kh + p.kw), c = i % (p.kh + p.kw);
+      const int tq = i0 + qi;
+      const int qy = wy * p.kh + tq / p.kw, qx = wx * p.kw + tq % p.kw;
+      const bool lq = tq < nk && qy < p.Sh && qx < p.Sw;
+      const int64_t slot = (int64_t)blockIdx.x * p.nkp + tq;
+      if (c < p.kh) bh[qi][c] = lq ? p.wbh[slot * p.kh + c] : 0.f;
+      else bw[qi][c - p.kh] = lq ? p.wbw[slot * p.kw + (c - p.kh)] : 0.f;
+    }
+    __syncthreads();
+    if (!live) continue;
+    for (int qi = 0; qi < 32; ++qi) {
+      if (!livel[qi]) continue;
+      float a = 0.f, dpv = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) { a = fmaf(ql[qi][d], k[d], a); dpv = fmaf(dl[qi][d], v[d], dpv); }
+      a = a * p.scale + bh[qi][ty] + bw[qi][tx];
+      const float pr = expf(a - lsel[qi]);
+      const float ds = pr * (dpv - dell[qi]) * p.scale;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) { dk[d] = fmaf(ds, ql[qi][d], dk[d]); dv[d] = fmaf(pr, dl[qi][d], dv[d]); }
+    }
+  }
+  if (!live) return;
+  float* o = p.dqkv + krow * C3 + head * HD;
+#pragma unroll
+  for (int d = 0; d < HD; d += 4) {
+    *reinterpret_cast<float4*>(o + C1 + d) = make_float4(dk[d], dk[d + 1], dk[d + 2], dk[d + 3]);
+    *reinterpret_cast<float4*>(o + 2 * C1 + d) = make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]);
+  }
+}
+static int64_t attn_f32_bwd_ws(int64_t G, int64_t Sh, int64_t Sw, int64_t heads, int64_t ws) {
+  const int64_t kh = ws > 0 ? ws : Sh, kw = ws > 0 ? ws : Sw;
+  const int64_t slots = G * ceil_div64(Sh, kh) * ceil_div64(Sw, kw) * heads * (ceil_div64(kh * kw, 64) * 64);
+  return slots * (2 + kh + kw);
+}
+extern "C" int64_t mfnet_attn_f32_bwd_workspace_floats(int64_t G, int64_t Sh, int64_t Sw, int64_t heads, int64_t ws) {
+  return (G > 0 && Sh > 0 && Sw > 0 && heads > 0 && ws >= 0) ? attn_f32_bwd_ws(G, Sh, Sw, heads, ws) : 0;
+}
+extern "C" int mfnet_attn_f32_bwd(const float* qkv, const float* qkv_bias, const float* th, const float* tw, const float* out, const float* dout,
+                                  float* dqkv, int64_t G, int64_t Sh, int64_t Sw, int64_t heads, int64_t hd, int64_t ws, float scale,
+                                  float* workspace, int64_t workspace_floats, hipStream_t stream) {
+  MF_CHECK_ARG(qkv && qkv_bias && th && tw && out && dout && dqkv && workspace, "attn_f32_bwd: null pointer");
+  MF_CHECK_ARG(G > 0 && Sh > 0 && Sw > 0 && heads > 0 && ws >= 0, "attn_f32_bwd: bad geometry");
+  const int64_t kh = ws > 0 ? ws : Sh, kw = ws > 0 ? ws : Sw;
+  MF_CHECK_ARG(kh <= AF_KMAX && kw <= AF_KMAX, "attn_f32_bwd: window / map side %lldx%lld exceeds %d tokens", (long long)kh, (long long)kw, AF_KMAX);
+  MF_CHECK_ARG(hd == 64 || hd == 80 || hd == 32, "attn_f32_bwd: head dim %lld (32, 64 and 80 are built)", (long long)hd);
+  MF_CHECK_ARG(workspace_floats >= attn_f32_bwd_ws(G, Sh, Sw, heads, ws), "attn_f32_bwd: workspace of %lld floats, need %lld",
+               (long long)workspace_floats, (long long)attn_f32_bwd_ws(G, Sh, Sw, heads, ws));
+  AttnF32BwdParams p;
+  p.qkv = qkv; p.qkv_bias = qkv_bias; p.th = th; p.tw = tw; p.out = out; p.dout = dout; p.dqkv = dqkv;
+  p.G = (int)G; p.Sh = (int)Sh; p.Sw = (int)Sw; p.heads = (int)heads; p.kh = (int)kh; p.kw = (int)kw;
+  p.nwh = (int)ceil_div64(Sh, kh); p.nww = (int)ceil_div64(Sw, kw); p.scale = scale;
+  const int64_t gx = G * p.nwh * p.nww * heads, gy = ceil_div64(kh * kw, 64);
+  MF_CHECK_ARG(gx < (1ll << 31) && gy <= 65535, "attn_f32_bwd: too many windows");
+  p.nkp = (int)(gy * 64);
+  const int64_t slots = gx * p.nkp;
+  p.lse = workspace; p.delta = workspace + slots; p.wbh = workspace + 2 * slots; p.wbw = p.wbh + slots * kh;
+  const dim3 grid((unsigned)gx, (unsigned)gy), block(64);
+  if (hd == 64) {
+    hipLaunchKernelGGL(attn_f32_bwd_dq_kernel<64>, grid, block, 0, stream, p);
+    hipLaunchKernelGGL(attn_f32_bwd_dkv_kernel<64>, grid, block, 0, stream, p);
+  } else if (hd == 80) {
+    hipLaunchKernelGGL(attn_f32_bwd_dq_kernel<80>, grid, block, 0, stream, p);
+    hipLaunchKernelGGL(attn_f32_bwd_dkv_kernel<80>, grid, block, 0, stream, p);
+  } else {
+    hipLaunchKernelGGL(attn_f32_bwd_dq_kernel<32>, grid, block, 0, stream, p);
+    hipLaunchKernelGGL(attn_f32_bwd_dkv_kernel<32>, grid, block, 0, stream, p);
+  }
+  MF_LAUNCH_CHECK("attn_f32_bwd");
   return MFNET_OK;
 }
 

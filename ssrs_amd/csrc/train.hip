@@ -311,21 +311,27 @@ extern "C" int mfnet_adapter_mix(const float* h, const float* ada, const float* 
 // dw[slot][0] += sum dh[x]*(ada[x]-ada[y]) ; dw[slot][1] += sum dh[y]*(ada[y]-ada[x]) over ADMIX_SLOTS slots (same-address
 // float atomics serialise: 2048 per address took 50 of the kernel's 61 us); the caller sums the slots
 #define ADMIX_SLOTS 16
+template <bool F32OUT>
 __global__ __launch_bounds__(256) void adapter_mix_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ ada,
                                                               const float* __restrict__ wx, const float* __restrict__ wy,
-                                                              bf16_t* __restrict__ dada, float* __restrict__ dw, int64_t half4) {
+                                                              void* __restrict__ dada_, float* __restrict__ dw, int64_t half4) {
   const float fx = wx[0], fy = wy[0];
   float sx = 0.f, sy = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < half4; i += (int64_t)gridDim.x * 256) {
     const float4 ax = reinterpret_cast<const float4*>(ada)[i], ay = reinterpret_cast<const float4*>(ada)[half4 + i];
     const float4 gx = reinterpret_cast<const float4*>(dh)[i], gy = reinterpret_cast<const float4*>(dh)[half4 + i];
-    u32x2_t o;
-    o.x = pack_bf16x2(fx * gx.x + (1 - fy) * gy.x, fx * gx.y + (1 - fy) * gy.y);
-    o.y = pack_bf16x2(fx * gx.z + (1 - fy) * gy.z, fx * gx.w + (1 - fy) * gy.w);
-    reinterpret_cast<u32x2_t*>(dada)[i] = o;
-    o.x = pack_bf16x2((1 - fx) * gx.x + fy * gy.x, (1 - fx) * gx.y + fy * gy.y);
-    o.y = pack_bf16x2((1 - fx) * gx.z + fy * gy.z, (1 - fx) * gx.w + fy * gy.w);
-    reinterpret_cast<u32x2_t*>(dada)[half4 + i] = o;
+    const float4 dx4 = make_float4(fx * gx.x + (1 - fy) * gy.x, fx * gx.y + (1 - fy) * gy.y, fx * gx.z + (1 - fy) * gy.z, fx * gx.w + (1 - fy) * gy.w);
+    const float4 dy4 = make_float4((1 - fx) * gx.x + fy * gy.x, (1 - fx) * gx.y + fy * gy.y, (1 - fx) * gx.z + fy * gy.z, (1 - fx) * gx.w + fy * gy.w);
+    if (F32OUT) {                        // the fp32 training path keeps the gradient in fp32
+      reinterpret_cast<float4*>(dada_)[i] = dx4;
+      reinterpret_cast<float4*>(dada_)[half4 + i] = dy4;
+    } else {
+      u32x2_t o;
+      o.x = pack_bf16x2(dx4.x, dx4.y); o.y = pack_bf16x2(dx4.z, dx4.w);
+      reinterpret_cast<u32x2_t*>(dada_)[i] = o;
+      o.x = pack_bf16x2(dy4.x, dy4.y); o.y = pack_bf16x2(dy4.z, dy4.w);
+      reinterpret_cast<u32x2_t*>(dada_)[half4 + i] = o;
+    }
     const float dxs = (ax.x - ay.x), dys = (ax.y - ay.y), dzs = (ax.z - ay.z), dws = (ax.w - ay.w);
     sx += gx.x * dxs + gx.y * dys + gx.z * dzs + gx.w * dws;
     sy -= gy.x * dxs + gy.y * dys + gy.z * dzs + gy.w * dws;
@@ -342,8 +348,16 @@ extern "C" int mfnet_adapter_mix_bwd(const float* dh, const float* ada, const fl
   (void)reserved;
   MF_CHECK_ARG(dh && ada && wx && wy && dada && dw && M % 2 == 0 && D % 4 == 0, "adapter_mix_bwd: bad args");
   if (M == 0) return MFNET_OK;
-  hipLaunchKernelGGL(adapter_mix_bwd_kernel, dim3(grid_for(M / 2 * D / 4, 512)), dim3(256), 0, stream, dh, ada, wx, wy, (bf16_t*)dada, dw, M / 2 * D / 4);
+  hipLaunchKernelGGL(adapter_mix_bwd_kernel<false>, dim3(grid_for(M / 2 * D / 4, 512)), dim3(256), 0, stream, dh, ada, wx, wy, dada, dw, M / 2 * D / 4);
   MF_LAUNCH_CHECK("adapter_mix_bwd");
+  return MFNET_OK;
+}
+extern "C" int mfnet_adapter_mix_bwd_f32(const float* dh, const float* ada, const float* wx, const float* wy, float* dada, float* dw, int64_t M,
+                                         int64_t D, hipStream_t stream) {
+  MF_CHECK_ARG(dh && ada && wx && wy && dada && dw && M % 2 == 0 && D % 4 == 0, "adapter_mix_bwd_f32: bad args");
+  if (M == 0) return MFNET_OK;
+  hipLaunchKernelGGL(adapter_mix_bwd_kernel<true>, dim3(grid_for(M / 2 * D / 4, 512)), dim3(256), 0, stream, dh, ada, wx, wy, (void*)dada, dw, M / 2 * D / 4);
+  MF_LAUNCH_CHECK("adapter_mix_bwd_f32");
   return MFNET_OK;
 }
 

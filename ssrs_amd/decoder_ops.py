@@ -75,7 +75,7 @@ def _wb_w3flipT(w):  # -> bf16 [I, 9*O], k = (8 - tap)*O + o: the weights of the
 def _conv3_fwd(x_bf, w, B, H, W):
     """-> (conv output fp32 [M, O], what the backward needs). Channels that are multiples of 64 (every 3x3 conv of MFNet) take the
     implicit-GEMM kernel and keep only x; others go through the column tensor."""
-    if x_bf.shape[1] % 64 == 0 and w.shape[0] % 64 == 0:
+    if ops.FP32 or (x_bf.shape[1] % 64 == 0 and w.shape[0] % 64 == 0):      # (fp32 training: ops.conv3x3 is im2col + the fp32 GEMM, any width)
         return ops.conv3x3(x_bf, _wb_w3(w), B, H, W), x_bf
     cols = ops.im2col3x3(x_bf, B, H, W)
     return ops.gemm(cols, _wb_w3(w), out_dtype=F32), cols
@@ -141,6 +141,7 @@ def fpn_fusion_params(model):
     return ps
 
 
+@ops.keeps_precision
 class FpnFusionFn(torch.autograd.Function):
     """deep [2B, h, w, 256] fp32 (RGB images first) -> res1 (perm 2), res2 (perm 1), res3, res4, all bf16
     [rows, 256]: fpn1..4{x,y} (unetformer_mmsam.py:494-516,545-552) + fusion1..4 (:251-281,553-556)."""
@@ -252,6 +253,7 @@ def convbn_params(seq):
     return [seq[0].weight, seq[1].weight, seq[1].bias]
 
 
+@ops.keeps_precision
 class ConvBN1x1Fn(torch.autograd.Function):
     """ConvBN(kernel 1) (unetformer_mmsam.py:43-51): x bf16 [M, Cin] -> fp32 [M, Cout]."""
 
@@ -357,6 +359,7 @@ def se_gates(se, rows, B, P):
     return s, z, g
 
 
+@ops.keeps_precision
 class BlockFn(torch.autograd.Function):
     """Block (unetformer_mmsam.py:200-217) = x + GlobalLocalAttention(BN(x)) (:105-198), then + Mlp(BN(.))
     (:86-102). x fp32 [B*H*W, C] -> fp32."""
@@ -457,6 +460,7 @@ def _fuse_bwd(dy, x, res, perm, m, geom, training, saved, gd):
     return dx, dres
 
 
+@ops.keeps_precision
 class WFFn(torch.autograd.Function):
     """WF (unetformer_mmsam.py:233-248): x fp32 [B*(H/2)*(W/2), C], res bf16 [B*H*W, Cin] (row order
     `perm`) -> ConvBNReLU6(fw0*pre_conv(res) + fw1*up2(x)) fp32 [B*H*W, C]."""
@@ -482,6 +486,7 @@ def frh_params(m):
                            m.shortcut[1].weight, m.shortcut[1].bias, m.proj[0].weight, m.proj[1].weight, m.proj[1].bias, m.proj[2].weight]
 
 
+@ops.keeps_precision
 class FRHFn(torch.autograd.Function):
     """FeatureRefinementHead (unetformer_mmsam.py:320-354) -> bf16 [B*H*W, C]."""
 
@@ -542,6 +547,7 @@ def seghead_params(head):
     return [head[0][0].weight, head[0][1].weight, head[0][1].bias, head[2][0].weight]
 
 
+@ops.keeps_precision
 class SegHeadFn(torch.autograd.Function):
     """segmentation_head + final bilinear upsample (unetformer_mmsam.py:439-441,454-455): x bf16
     [B*H*W, C] -> logits fp32 [B, ncls, s*H, s*W]. drop_mask [B, C] of {0, 1/(1-p)} = Dropout2d."""
@@ -587,7 +593,7 @@ def to_rows(x_nchw, dtype=None):
     """(B,C,H,W) -> contiguous [B*H*W, C] (layout change only)."""
     B, C, H, W = x_nchw.shape
     t = x_nchw.permute(0, 2, 3, 1).reshape(B * H * W, C)
-    return t.contiguous() if dtype is None else t.to(dtype).contiguous()
+    return t.contiguous() if dtype is None else t.to(ops._odt(dtype)).contiguous()
 
 
 def to_nchw(rows, B, H, W):

@@ -5,7 +5,8 @@ its contractions on bf16 MFMA (2e-2 on the logits). This path keeps every activa
 the fp32 MFMA (csrc/fp32.hip: `mfnet_gemm_f32`, a k-ordered fp32 fma chain) and the attention in fp32 (`mfnet_attn_f32`,
 `mfnet_gla_attn_fwd_f32`), so the logits agree with the fp32 reference to 1e-4 relative. It reuses the fp32 kernels the
 training path already has for everything that is not a contraction (LayerNorm, BatchNorm, SE gates, pooling, depthwise
-convolutions, the up-sampling fusions). Forward only: training stays on the bf16 path, which owns the backward kernels.
+convolutions, the up-sampling fusions). Forward only, no saved tensors: fp32 TRAINING runs the ordinary module path in
+`ops.precision("fp32")` mode (unetformer_mmsam.UNetFormer.forward), which owns the backward passes.
 
 Same module objects, same parameters - the functions below only read `model`'s tensors."""
 from __future__ import annotations
@@ -22,34 +23,8 @@ F32 = torch.float32
 
 
 # ---------------------------------------------------------------------------------------------- kernels
-def gemm32(a, w, bias=None, act=0, residual=None, res_row_mod=0, alpha=1.0, out=None, accumulate=False):
-    """out = act(alpha * a @ w^T + bias) (+ residual) (+ out if accumulate). a [M,K], w [N,K] fp32 (unit inner stride, row
-    strides multiples of 4); out [M,N] fp32 (any row stride). act: 0 none, 1 GELU(erf), 3 ReLU6, 6 ReLU."""
-    ops._chk(a, w, bias, residual, out)
-    assert a.dtype == F32 and w.dtype == F32 and a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1
-    M, K = a.shape
-    N = w.shape[0]
-    assert w.shape[1] == K
-    if out is None:
-        assert not accumulate
-        out = torch.empty((M, N), dtype=F32, device=a.device)
-    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == F32
-    if residual is not None:
-        assert residual.dtype == F32 and residual.stride(1) == 1 and residual.shape[1] == N
-    call("mfnet_gemm_f32", a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), M, N, K, ops._p(bias), float(alpha), int(act),
-         ops._p(residual), residual.stride(0) if residual is not None else 0, int(res_row_mod), out.data_ptr(), out.stride(0),
-         1 if accumulate else 0, ops._stream(a))
-    return out
-
-
-def attn32(qkv, qkv_bias, th, tw, G, Sh, Sw, heads, ws, scale):
-    ops._chk(qkv, qkv_bias, th, tw)
-    assert qkv.is_contiguous() and qkv.dtype == F32 and th.is_contiguous() and tw.is_contiguous()
-    D3 = qkv.shape[1]
-    out = torch.empty((qkv.shape[0], D3 // 3), dtype=F32, device=qkv.device)
-    call("mfnet_attn_f32", qkv.data_ptr(), qkv_bias.data_ptr(), th.data_ptr(), tw.data_ptr(), out.data_ptr(), G, Sh, Sw, heads,
-         D3 // (3 * heads), ws, float(scale), ops._stream(qkv))
-    return out
+gemm32 = ops.gemm_f32
+attn32 = ops.attn_f32
 
 
 def im2col_patch32(rgb, dsm, patch=16):
@@ -288,7 +263,7 @@ def decoder32(dec, res1, res2, res3, res4, B, S, h, w, perms=(2, 1)):
 def forward_fp32(model, x, y):
     """UNetFormer.forward (unetformer_mmsam.py:533-563) in fp32: x (B,3,H,W), y (B,H,W) or (B,3,H,W) -> logits (B,ncls,H,W)."""
     if model.training:
-        raise NotImplementedError("the fp32 path is forward-only in eval mode (model.eval()); training runs on the bf16 MFMA path")
+        raise NotImplementedError("forward_fp32 is the eval-mode forward; fp32 training goes through UNetFormer.forward")
     h, w = x.shape[-2:]
     B = x.shape[0]
     deep = encoder32(model.image_encoder, x, y)

@@ -28,6 +28,56 @@ LN_BWD_TRACE = None
 KERNEL_TRACE = None
 
 
+# fp32 training (the reference trains in fp32: trainer.py:146-159). While FP32 is set, every request for a bf16 activation,
+# gradient or weight image is answered in fp32 (_odt) and the wrappers below route fp32 operands of the bf16-only MFMA kernels to
+# mfnet_gemm_f32 and the fp32 twins (attention, GLA attention, up-sampling, adapter mix). The module backward passes (vit.py,
+# vit_adapter.py, decoder_ops.py) are the same code in both modes; autograd Functions remember the mode of their forward
+# (`keeps_precision`), so a backward pass runs in the mode its forward ran in.
+FP32 = False
+
+
+def _odt(dt):
+    return torch.float32 if (FP32 and dt == torch.bfloat16) else dt
+
+
+class precision:
+    """`with ops.precision("fp32"):` - the calls inside compute in fp32 (see FP32)."""
+
+    def __init__(self, name):
+        if name not in ("bf16", "fp32"):
+            raise ValueError(f"precision {name!r}: 'bf16' (default) or 'fp32'")
+        self.want = name == "fp32"
+
+    def __enter__(self):
+        global FP32
+        self.prev, FP32 = FP32, self.want
+        return self
+
+    def __exit__(self, *exc):
+        global FP32
+        FP32 = self.prev
+        return False
+
+
+def keeps_precision(cls):
+    """class decorator for torch.autograd.Function: the backward runs in the precision mode its forward ran in"""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args):
+        ctx._mfnet_fp32 = FP32
+        return fwd(ctx, *args)
+
+    def backward(ctx, *grads):
+        global FP32
+        prev, FP32 = FP32, ctx._mfnet_fp32
+        try:
+            return bwd(ctx, *grads)
+        finally:
+            FP32 = prev
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
+
+
 def tcall(name, nbytes, flops, *args):
     """call(name, *args) with its algorithmic bytes / flops noted for KERNEL_TRACE (each operand counted once)."""
     if KERNEL_TRACE is None:
@@ -67,9 +117,80 @@ def _rows2d(t: torch.Tensor):
     return t2, t2.shape[0], t2.shape[1], t2.stride(0)
 
 
+def gemm_f32(a, w, bias=None, act=0, residual=None, res_row_mod=0, alpha=1.0, out=None, accumulate=False):
+    """out = act(alpha * a @ w^T + bias) (+ residual) (+ out if accumulate). a [M,K], w [N,K] fp32 (unit inner stride, row
+    strides multiples of 4); out [M,N] fp32 (any row stride). act: 0 none, 1 GELU(erf), 3 ReLU6, 6 ReLU."""
+    _chk(a, w, bias, residual, out)
+    assert a.dtype == torch.float32 and w.dtype == torch.float32 and a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    if out is None:
+        assert not accumulate
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.stride(1) == 1 and residual.shape[1] == N
+    call("mfnet_gemm_f32", a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), M, N, K, _p(bias), float(alpha), int(act),
+         _p(residual), residual.stride(0) if residual is not None else 0, int(res_row_mod), out.data_ptr(), out.stride(0),
+         1 if accumulate else 0, _stream(a))
+    return out
+
+
+def _t32(x):
+    """contiguous transpose of a 2-D fp32 view (a copy: the fp32 GEMM reads both operands k-major)"""
+    return x.t().contiguous()
+
+
+def _gemm_route32(a, w, bias, U, V, rows_per_group, n_groups, lr_scale, act, aux, want_pre, residual, res_row_mod, out, pre_out=None):
+    """ops.gemm's contract on fp32 operands: a @ w^T (+ bias + lr_scale * U V_g^T) -> act -> (+ residual), as mfnet_gemm_f32 launches
+    plus the elementwise kernels for the epilogues the fp32 GEMM does not fuse. act: 0, 1 GELU, 2 x gelu'(aux), 3 ReLU6,
+    4 x relu6'(aux), 5 ReLU6 after the residual."""
+    a2, M, K, lda = _rows2d(a)
+    assert w.dtype == torch.float32 and w.dim() == 2 and w.shape[1] == K and w.stride(1) == 1
+    N = w.shape[0]
+    if out is not None:
+        assert out.dtype == torch.float32 and out.dim() == 2
+    fused_res = residual is not None and act in (0, 3) and not want_pre and U is None
+    direct = U is None and not want_pre and act in (0, 1, 3) and (residual is None or fused_res)
+    if direct:                              # the fp32 GEMM's own epilogue: act, then the residual
+        return gemm_f32(a2, w, bias=bias, act=act, residual=residual, res_row_mod=res_row_mod, out=out)
+    lin_res = residual if (act in (0, 5) and not want_pre) else None           # the residual joins before anything non-linear happens
+    plain = act == 0 and not want_pre
+    pre = gemm_f32(a2, w, bias=bias, residual=lin_res, res_row_mod=res_row_mod if lin_res is not None else 0,
+                   out=out if plain else pre_out)
+    if U is not None:
+        G = n_groups if V.dim() == 3 else 1
+        for g in range(G):
+            rows = slice(g * rows_per_group, (g + 1) * rows_per_group) if G > 1 else slice(0, M)
+            gemm_f32(U[rows], V[g] if V.dim() == 3 else V, alpha=lr_scale, out=pre[rows], accumulate=True)
+    if plain:
+        return pre
+    if act == 0:                            # want_pre without an activation: pre, and pre + residual
+        res = add3(pre, residual, out=out) if residual is not None else pre
+        return res, pre
+    if act == 1:
+        res = gelu_fwd(pre)
+    elif act == 2:
+        res = gelu_bwd(aux.contiguous(), pre)
+    elif act in (3, 5):
+        res = _relu6(pre)
+    elif act == 4:
+        res = act_bwd(pre, aux.contiguous(), ACT_RELU6, out_dtype=torch.float32)
+    else:
+        raise MfnetError(f"fp32 GEMM route: activation code {act}")
+    if residual is not None and act != 5:
+        res = add3(res, residual)
+    if out is not None:
+        out.copy_(res)
+        res = out
+    return (res, pre) if want_pre else res
+
+
 # ------------------------------------------------------------------------------------------ LayerNorm
 def layernorm_fwd(x, gamma, beta, eps, out_dtype=torch.bfloat16, want_stats=True):
     _chk(x, gamma, beta)
+    out_dtype = _odt(out_dtype)
     x2, rows, C, ldx = _rows2d(x)
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
@@ -113,6 +234,9 @@ def lora_down_mix(x, A, wx=None, wy=None):
 def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, want_f32=True, want_bf16=False, dgamma=None, dbeta=None):
     """dx = LN'(dy) [+ dres]; returns (dx_f32 | None, dx_bf16 | None). dgamma/dbeta are accumulated into."""
     _chk(dy, x, mean, rstd, gamma, dres)
+    if FP32 and want_bf16:                  # fp32 training: the "bf16 copy" of the gradient is the fp32 gradient itself
+        dx, _ = layernorm_bwd(dy, x, mean, rstd, gamma, dres, True, False, dgamma, dbeta)
+        return (dx if want_f32 else None), dx
     dy2, rows, C, lddy = _rows2d(dy)
     x2, _, _, ldx = _rows2d(x)
     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_f32 else None
@@ -193,6 +317,12 @@ def gemm(a, w, *, bias=None, U=None, V=None, rows_per_group=0, n_groups=1, lr_sc
     V: [G,N,R] fp32. act: 0 none, 1 gelu (want_pre also returns the pre-activation), 2 multiply by
     gelu'(aux). Returns out or (out, pre)."""
     _chk(a, w, bias, U, V, aux, residual, out)
+    if a.dtype == torch.float32:
+        assert k_splits == 1 and not tile
+        if U is not None and U.shape[-1] % 4:
+            padc = 4 - U.shape[-1] % 4
+            U, V = torch.nn.functional.pad(U, (0, padc)), torch.nn.functional.pad(V, (0, padc))
+        return _gemm_route32(a, w, bias, U, V, rows_per_group, n_groups, lr_scale, act, aux, want_pre, residual, res_row_mod, out)
     assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
     a2, M, K, lda = _rows2d(a)
     N, K2 = w.shape
@@ -237,6 +367,18 @@ def gemm_grouped(a, w, *, bias=None, rows_per_group, act=0, aux=None, want_pre=F
     """Per-group weights: a [M,K] bf16, w [G,N,K] bf16, bias [G,N] fp32 | None; rows [g*rpg, (g+1)*rpg) use w[g], bias[g]
     (the per-modality adapters in one launch). Otherwise as gemm (no low-rank term)."""
     _chk(a, w, bias, aux, residual, out)
+    if a.dtype == torch.float32:
+        a2, M, K, lda = _rows2d(a)
+        G, N = w.shape[0], w.shape[1]
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        pre = torch.empty((M, N), dtype=torch.float32, device=a.device) if want_pre else None
+        for g in range(G):
+            rows = slice(g * rows_per_group, (g + 1) * rows_per_group)
+            _gemm_route32(a2[rows], w[g], bias[g] if bias is not None else None, None, None, 0, 1, 1.0, act,
+                          aux[rows] if aux is not None else None, want_pre, residual[rows] if residual is not None else None, 0,
+                          out[rows], pre[rows] if want_pre else None)
+        return (out, pre) if want_pre else out
     assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.dim() == 3 and w.is_contiguous()
     a2, M, K, lda = _rows2d(a)
     G, N, K2 = w.shape
@@ -269,6 +411,11 @@ def skinny_nt(x, wt, scale=1.0, out=None, rows_per_group=0):
     if out is None:
         Rp = (R + 3) // 4 * 4
         out = torch.empty((M, Rp), dtype=torch.float32, device=x.device)[:, :R]
+    if x.dtype == torch.float32:
+        for g in range(G):
+            rows = slice(g * rows_per_group, (g + 1) * rows_per_group) if G > 1 else slice(0, M)
+            gemm_f32(x2[rows], wt[g] if G > 1 else wt.reshape(R, K), alpha=scale, out=out[rows])
+        return out
     for c0 in range(0, R, 16):
         c1 = min(R, c0 + 16)
         wc, oc = wt[..., c0:c1, :], out[:, c0:c1]
@@ -337,6 +484,15 @@ def skinny_tn(y, u, transposed: bool, scale=1.0, out=None, n_groups=1, lazy=Fals
     y2, M, C, ldy = _rows2d(y)
     R = u.shape[1]
     assert u.dtype == torch.float32 and u.stride(1) == 1 and u.shape[0] == M and M % n_groups == 0
+    if y.dtype == torch.float32:
+        Mg = M // n_groups
+        res = out if out is not None else torch.empty((n_groups, R, C) if transposed else (n_groups, C, R), dtype=torch.float32, device=y.device)
+        r3 = res if res.dim() == 3 else res[None]
+        for g in range(n_groups):
+            yt, ut = _t32(y2[g * Mg:(g + 1) * Mg]), _t32(u[g * Mg:(g + 1) * Mg])
+            gemm_f32(ut, yt, alpha=scale, out=r3[g], accumulate=out is not None) if transposed else \
+                gemm_f32(yt, ut, alpha=scale, out=r3[g], accumulate=out is not None)
+        return res[0] if (n_groups == 1 and res.dim() == 3) else res
     if R % 4:                # LoRA rank 2: zero columns up to the next width the kernel is built for (a [M, 4] copy)
         assert out is None
         res = skinny_tn(y, torch.nn.functional.pad(u, (0, 4 - R % 4)), transposed, scale, None, n_groups, False)
@@ -367,6 +523,9 @@ def skinny_tn(y, u, transposed: bool, scale=1.0, out=None, n_groups=1, lazy=Fals
 
 def cast(x, dtype):
     _chk(x)
+    dtype = _odt(dtype)
+    if x.dtype == dtype and FP32:
+        return x
     assert x.is_contiguous() and x.numel() % 8 == 0
     y = torch.empty(x.shape, dtype=dtype, device=x.device)
     call("mfnet_cast", x.data_ptr(), _DT[x.dtype], y.data_ptr(), _DT[dtype], x.numel(), _stream(x))
@@ -387,6 +546,8 @@ def remember_bf16_twin(d, d_bf):
 def bf16_of(d2):
     """bf16 copy of the fp32 gradient d2: the stored twin if d2 is that very tensor, else a cast launch."""
     t, _twin[0] = _twin[0], None
+    if FP32:
+        return d2
     if t is not None and t[0].data_ptr() == d2.data_ptr() and t[0].numel() == d2.numel() and t[0]._version == t[2] \
             and d2.is_contiguous():
         return t[1].view(d2.shape)
@@ -418,6 +579,10 @@ def im2col_patch(rgb, dsm, patch=16):
     ych = 1 if dsm.dim() == 3 else int(dsm.shape[1])
     if tuple(dsm.shape) != ((B, H, W) if dsm.dim() == 3 else (B, ych, H, W)) or rgb.shape[1] != 3 or ych not in (1, 3):
         raise ValueError(f"im2col_patch: rgb {tuple(rgb.shape)} and second modality {tuple(dsm.shape)} do not match")
+    if FP32:
+        cols = torch.empty((2 * B * (H // patch) * (W // patch), 3 * patch * patch), dtype=torch.float32, device=rgb.device)
+        call("mfnet_im2col_patch_f32", rgb.data_ptr(), dsm.data_ptr(), ych, cols.data_ptr(), B, H, W, patch, _stream(rgb))
+        return cols
     cols = torch.empty((2 * B * (H // patch) * (W // patch), 3 * patch * patch), dtype=torch.bfloat16, device=rgb.device)
     tcall("mfnet_im2col_patch", (rgb.numel() + dsm.numel()) * 4 + cols.numel() * 2, 0, rgb.data_ptr(), dsm.data_ptr(), ych, cols.data_ptr(), B, H, W, patch, _stream(rgb))
     return cols
@@ -426,6 +591,11 @@ def im2col_patch(rgb, dsm, patch=16):
 def im2col3x3(x, G, H, W):
     _chk(x)
     C = x.shape[-1]
+    if x.dtype == torch.float32:
+        assert x.is_contiguous()
+        cols = torch.empty((G * H * W, 9 * C), dtype=torch.float32, device=x.device)
+        call("mfnet_im2col3x3_f32", x.data_ptr(), cols.data_ptr(), G, H, W, C, _stream(x))
+        return cols
     assert x.is_contiguous() and x.dtype == torch.bfloat16
     cols = torch.empty((G * H * W, 9 * C), dtype=torch.bfloat16, device=x.device)
     call("mfnet_im2col3x3", x.data_ptr(), cols.data_ptr(), G, H, W, C, _stream(x))
@@ -444,6 +614,8 @@ def conv3x3(x, w, G, H, W, out_dtype=torch.float32):
     """3x3 / pad 1 convolution as an implicit GEMM: x [G*H*W, C] bf16 channels-last rows (C % 64 == 0), w [N, 9*C] bf16 with
     k = tap*C + c -> [G*H*W, N]. The data gradient is the same call on dy with the flipped, transposed weights."""
     _chk(x, w)
+    if x.dtype == torch.float32:             # fp32 training: the column tensor and the fp32 GEMM (any C % 4 == 0)
+        return gemm_f32(im2col3x3(x.contiguous(), G, H, W), w)
     assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 2 and w.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1
     C, N = x.shape[1], w.shape[0]
     assert x.shape[0] == G * H * W and w.shape[1] == 9 * C
@@ -456,6 +628,9 @@ def conv3x3_wgrad(dy, x, G, H, W, want_bias=False):
     """weight gradient of conv3x3: [N, 9*C] fp32 (k = tap*C + c) as a SplitSum over the row splits (a plain tensor when there is
     one split); dy [G*H*W, N] bf16, x [G*H*W, C] bf16, C % 64 == 0. want_bias: (dW, db) with db = column sums of dy."""
     _chk(dy, x)
+    if dy.dtype == torch.float32:
+        dW = gemm_f32(_t32(dy), _t32(im2col3x3(x.contiguous(), G, H, W)))
+        return (dW, SplitSum(colsum(dy.contiguous(), 1, dy.shape[0])[0])) if want_bias else dW
     assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.stride(-1) == 1 and x.stride(-1) == 1
     M, N = dy.shape
     C = x.shape[1]
@@ -576,6 +751,30 @@ def attn_bwd(qkv, qkv_bias, tbl, tblT, out, dout, lse, G, Sh, Sw, heads, ws, Lh,
     return dqkv
 
 
+def attn_f32(qkv, qkv_bias, th, tw, G, Sh, Sw, heads, ws, scale):
+    """SAM ViT attention in fp32 (csrc/fp32.hip): qkv [G*Sh*Sw, 3D] fp32, th / tw the resized fp32 rel-pos tables -> out [G*Sh*Sw, D]."""
+    _chk(qkv, qkv_bias, th, tw)
+    assert qkv.is_contiguous() and qkv.dtype == torch.float32 and th.is_contiguous() and tw.is_contiguous()
+    D3 = qkv.shape[1]
+    out = torch.empty((qkv.shape[0], D3 // 3), dtype=torch.float32, device=qkv.device)
+    call("mfnet_attn_f32", qkv.data_ptr(), qkv_bias.data_ptr(), th.data_ptr(), tw.data_ptr(), out.data_ptr(), G, Sh, Sw, heads,
+         D3 // (3 * heads), ws, float(scale), _stream(qkv))
+    return out
+
+
+def attn_f32_bwd(qkv, qkv_bias, th, tw, out, dout, G, Sh, Sw, heads, ws, scale):
+    """dqkv of attn_f32 (tables and qkv bias frozen)."""
+    _chk(qkv, qkv_bias, th, tw, out, dout)
+    assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and qkv.dtype == out.dtype == dout.dtype == torch.float32
+    D3 = qkv.shape[1]
+    dqkv = torch.empty_like(qkv)
+    nws = int(_lib.lib().mfnet_attn_f32_bwd_workspace_floats(G, Sh, Sw, heads, ws))
+    wsp = torch.empty(nws, dtype=torch.float32, device=qkv.device)
+    call("mfnet_attn_f32_bwd", qkv.data_ptr(), qkv_bias.data_ptr(), th.data_ptr(), tw.data_ptr(), out.data_ptr(), dout.data_ptr(),
+         dqkv.data_ptr(), G, Sh, Sw, heads, D3 // (3 * heads), ws, float(scale), wsp.data_ptr(), nws, _stream(qkv))
+    return dqkv
+
+
 # ------------------------------------------------------------------------------------------ train / infer glue
 def ce_loss_fwd(logits, target, weight=None, ignore_index=-100, want_pred=False):
     _chk(logits, target, weight)
@@ -657,8 +856,12 @@ def adapter_mix(h, ada, wx, wy, out=None):
 
 def adapter_mix_bwd(dh, ada, wx, wy):
     M, D = dh.shape
-    dada = torch.empty((M, D), dtype=torch.bfloat16, device=dh.device)
     dw = zeros((16, 2), dh.device)                       # 16 slots of (d wx, d wy); summed by the gradient delivery
+    if FP32:
+        dada = torch.empty((M, D), dtype=torch.float32, device=dh.device)
+        call("mfnet_adapter_mix_bwd_f32", dh.data_ptr(), ada.data_ptr(), wx.data_ptr(), wy.data_ptr(), dada.data_ptr(), dw.data_ptr(), M, D, _stream(dh))
+        return dada, SplitSum(dw)
+    dada = torch.empty((M, D), dtype=torch.bfloat16, device=dh.device)
     call("mfnet_adapter_mix_bwd", dh.data_ptr(), ada.data_ptr(), wx.data_ptr(), wy.data_ptr(), dada.data_ptr(),
          dw.data_ptr(), None, M, D, _stream(dh))
     return dada, SplitSum(dw)
@@ -679,6 +882,8 @@ def bias_grad(dy, out=None):
 def add_bf16(a, b, out):
     _chk(a, b, out)
     assert a.is_contiguous() and b.is_contiguous() and out.is_contiguous()
+    if a.dtype == torch.float32:
+        return add3(a, b, out=out)
     call("mfnet_add_bf16", a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream(a))
     return out
 
@@ -736,6 +941,19 @@ def gemm_tn_grouped(dy, x, n_groups, want_bias=False):
     in one launch -> SplitSum of shape [G, N, K] (index it per group and hand the pieces to deliver). want_bias: also the
     column sums of dy per group (the bias gradients), from the same launch -> (dW, db) with db a SplitSum [G, N]."""
     _chk(dy, x)
+    if dy.dtype == torch.float32:
+        d2, M, N, ldy = _rows2d(dy)
+        x2, M2, K, ldx = _rows2d(x)
+        assert M == M2 and M % n_groups == 0 and x.dtype == torch.float32
+        Mg = M // n_groups
+        part = torch.empty((1, n_groups, N, K), dtype=torch.float32, device=dy.device)
+        bpart = torch.empty((1, n_groups, N), dtype=torch.float32, device=dy.device) if want_bias else None
+        for g in range(n_groups):
+            dg = d2[g * Mg:(g + 1) * Mg]
+            gemm_f32(_t32(dg), _t32(x2[g * Mg:(g + 1) * Mg]), out=part[0, g])
+            if want_bias:
+                bpart[0, g].copy_(colsum(dg.contiguous(), 1, Mg)[0].view(N))
+        return (SplitSum(part), SplitSum(bpart)) if want_bias else SplitSum(part)
     assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.stride(-1) == 1 and x.stride(-1) == 1
     d2, M, N, ldy = _rows2d(dy)
     x2, M2, K, ldx = _rows2d(x)
@@ -760,6 +978,12 @@ def gemm_tn(dy, x, lazy=False, want_bias=False):
     also leaves the column sums of dy (the layer's bias gradient) -> (dW, db), db always a SplitSum over [splits, N]
     partial rows (view its .part to fold further, e.g. the 4 taps of a transposed conv)."""
     _chk(dy, x)
+    if dy.dtype == torch.float32:
+        d2, M, N, ldy = _rows2d(dy)
+        x2, M2, K, ldx = _rows2d(x)
+        assert M == M2 and x.dtype == torch.float32
+        dW = gemm_f32(_t32(d2), _t32(x2))
+        return (dW, SplitSum(colsum(d2.contiguous(), 1, M)[0])) if want_bias else dW
     assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.stride(-1) == 1 and x.stride(-1) == 1
     d2, M, N, ldy = _rows2d(dy)
     x2, M2, K, ldx = _rows2d(x)
@@ -871,6 +1095,7 @@ def bn_forward(x, gamma, beta, run_mean, run_var, nbt, training, eps=1e-5, momen
                rows_per_image=0, out_dtype=torch.float32, out2_dtype=None):
     """BatchNorm2d on a channels-last [rows, C] map. -> (y, y2 | None, mean, rstd)."""
     _chk(x, gamma, beta)
+    out_dtype, out2_dtype = _odt(out_dtype), (_odt(out2_dtype) if out2_dtype is not None else None)
     rows, C = x.shape
     assert x.is_contiguous()
     st = torch.empty((2, C), dtype=torch.float32, device=x.device)
@@ -922,6 +1147,7 @@ def bn_forward(x, gamma, beta, run_mean, run_var, nbt, training, eps=1e-5, momen
 def bn_backward(dy, x, mean, rstd, gamma, beta, training, act=ACT_NONE, chan_scale=None, rows_per_image=0, dx_dtype=torch.float32):
     """-> (dx, dgamma, dbeta)."""
     _chk(dy, x)
+    dx_dtype = _odt(dx_dtype)
     rows, C = x.shape
     assert dy.is_contiguous() and x.is_contiguous() and dy.shape == x.shape
     sums = zeros((2, C), x.device)
@@ -945,15 +1171,19 @@ def bn_backward(dy, x, mean, rstd, gamma, beta, training, act=ACT_NONE, chan_sca
 def act(x, kind, out_dtype=None):
     _chk(x)
     assert x.is_contiguous()
-    y = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
+    y = torch.empty(x.shape, dtype=_odt(out_dtype or x.dtype), device=x.device)
     call("mfnet_act", x.data_ptr(), _dt(x), y.data_ptr(), _dt(y), kind, x.numel(), _stream(x))
     return y
+
+
+def _relu6(x):
+    return act(x, ACT_RELU6)
 
 
 def act_bwd(dy, ref, kind, out_dtype=torch.bfloat16):
     _chk(dy, ref)
     assert dy.is_contiguous() and ref.is_contiguous() and dy.shape == ref.shape
-    dx = torch.empty(dy.shape, dtype=out_dtype, device=dy.device)
+    dx = torch.empty(dy.shape, dtype=_odt(out_dtype), device=dy.device)
     call("mfnet_act_bwd", dy.data_ptr(), _dt(dy), ref.data_ptr(), _dt(ref), dx.data_ptr(), _dt(dx), kind, dy.numel(), _stream(dy))
     return dx
 
@@ -988,9 +1218,9 @@ def dwconv_bwd(dy, x, w, B, H, W, k, ext, want_bias=False):
 
 def gla_attn_fwd(qkv, table, B, H, W, heads, scale):
     _chk(qkv, table)
-    assert qkv.is_contiguous() and qkv.dtype == torch.bfloat16 and table.is_contiguous() and table.dtype == torch.float32
+    assert qkv.is_contiguous() and qkv.dtype in (torch.bfloat16, torch.float32) and table.is_contiguous() and table.dtype == torch.float32
     out = torch.empty((qkv.shape[0], heads * 8), dtype=torch.float32, device=qkv.device)
-    call("mfnet_gla_attn_fwd", qkv.data_ptr(), table.data_ptr(), out.data_ptr(), B, H, W, heads, qkv.shape[1] // (3 * heads), 8, float(scale), _stream(qkv))
+    call("mfnet_gla_attn_fwd_f32" if qkv.dtype == torch.float32 else "mfnet_gla_attn_fwd", qkv.data_ptr(), table.data_ptr(), out.data_ptr(), B, H, W, heads, qkv.shape[1] // (3 * heads), 8, float(scale), _stream(qkv))
     return out
 
 
@@ -999,7 +1229,7 @@ def gla_attn_bwd(qkv, table, dout, B, H, W, heads, scale):
     assert dout.is_contiguous() and dout.dtype == torch.float32
     dqkv = torch.empty_like(qkv)
     dtable = zeros(table.shape, table.device)
-    call("mfnet_gla_attn_bwd", qkv.data_ptr(), table.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), dtable.data_ptr(), B, H, W, heads,
+    call("mfnet_gla_attn_bwd_f32" if qkv.dtype == torch.float32 else "mfnet_gla_attn_bwd", qkv.data_ptr(), table.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), dtable.data_ptr(), B, H, W, heads,
          qkv.shape[1] // (3 * heads), 8, float(scale), _stream(qkv))
     return dqkv, dtable
 
@@ -1024,7 +1254,7 @@ def upfuse_fwd(x, skip, perm, w, eps, B, H, W, out_dtype=torch.bfloat16):
     _chk(x, skip, w)
     C = x.shape[-1]
     assert x.is_contiguous() and x.dtype == torch.float32 and skip.is_contiguous() and skip.shape == (B * H * W, C)
-    out = torch.empty((B * H * W, C), dtype=out_dtype, device=x.device)
+    out = torch.empty((B * H * W, C), dtype=_odt(out_dtype), device=x.device)
     tcall("mfnet_upfuse_fwd", x.numel() * 4 + skip.numel() * skip.element_size() + out.numel() * out.element_size(), 0, x.data_ptr(), skip.data_ptr(), _dt(skip), perm, w.data_ptr(), float(eps), out.data_ptr(), _dt(out), B, H, W, C, _stream(x))
     return out
 
@@ -1035,7 +1265,7 @@ def upfuse_bwd(df, x, skip, perm, w, eps, B, H, W, dskip_dtype=torch.bfloat16):
     C = x.shape[-1]
     assert df.is_contiguous() and df.dtype == torch.float32
     dx = torch.empty_like(x)
-    dskip = torch.empty(skip.shape, dtype=dskip_dtype, device=x.device)
+    dskip = torch.empty(skip.shape, dtype=_odt(dskip_dtype), device=x.device)
     dw = zeros(2, x.device)
     sums = torch.empty(64, dtype=torch.float32, device=x.device)          # 32 slots x 2, zeroed by the entry point
     tcall("mfnet_upfuse_bwd", df.numel() * 4 + x.numel() * 8 + skip.numel() * skip.element_size() + dskip.numel() * dskip.element_size(), 0, df.data_ptr(), x.data_ptr(), skip.data_ptr(), _dt(skip), perm, w.data_ptr(), float(eps), dx.data_ptr(),
@@ -1054,6 +1284,10 @@ def up_final_fwd(x, B, h, w, ncls, s):
 def up_final_bwd(dlogits, ldx, B, h, w, ncls, s):
     _chk(dlogits)
     assert dlogits.is_contiguous() and dlogits.dtype == torch.float32
+    if FP32:
+        dx = torch.empty((B * h * w, ldx), dtype=torch.float32, device=dlogits.device)
+        call("mfnet_up_final_bwd_f32", dlogits.data_ptr(), dx.data_ptr(), ldx, B, h, w, ncls, s, _stream(dlogits))
+        return dx
     dx = torch.empty((B * h * w, ldx), dtype=torch.bfloat16, device=dlogits.device)
     tcall("mfnet_up_final_bwd", dlogits.numel() * 4 + B * h * w * ncls * 2, 0, dlogits.data_ptr(), dx.data_ptr(), ldx, B, h, w, ncls, s, _stream(dlogits))
     return dx
@@ -1105,7 +1339,7 @@ def se_gate_bwd(dg, pooled_sum, P, W1, W2, relu6, z, g, has_bias):
 def se_scale_sum(rx, ry, gx, gy, B, P, out_dtype=torch.bfloat16):
     _chk(rx, ry, gx, gy)
     C = rx.shape[-1]
-    out = torch.empty((B * P, C), dtype=out_dtype, device=rx.device)
+    out = torch.empty((B * P, C), dtype=_odt(out_dtype), device=rx.device)
     call("mfnet_se_scale_sum", rx.data_ptr(), _dt(rx), ry.data_ptr(), _dt(ry), gx.data_ptr(), gy.data_ptr(), out.data_ptr(), _dt(out), B, P, C, _stream(rx))
     return out
 
@@ -1114,8 +1348,8 @@ def se_bwd_apply(dres, gx, gy, dpx, dpy, B, P, dtype_x=None, dtype_y=None, out_x
     _chk(dres)
     C = dres.shape[-1]
     assert dres.is_contiguous()
-    drx = out_x if out_x is not None else torch.empty((B * P, C), dtype=dtype_x, device=dres.device)
-    dry = out_y if out_y is not None else torch.empty((B * P, C), dtype=dtype_y, device=dres.device)
+    drx = out_x if out_x is not None else torch.empty((B * P, C), dtype=_odt(dtype_x), device=dres.device)
+    dry = out_y if out_y is not None else torch.empty((B * P, C), dtype=_odt(dtype_y), device=dres.device)
     assert drx.is_contiguous() and dry.is_contiguous()
     call("mfnet_se_bwd_apply", dres.data_ptr(), _dt(dres), gx.data_ptr(), gy.data_ptr(), dpx.data_ptr(), dpy.data_ptr(), drx.data_ptr(),
          _dt(drx), dry.data_ptr(), _dt(dry), B, P, C, _stream(dres))

@@ -290,8 +290,9 @@ class UNetFormer(nn.Module):
                  sam_checkpoint=None, args=None, precision=None):
         super().__init__()
         # "bf16" (default): bf16 MFMA contractions with fp32 accumulation, training + inference, logits within 2e-2 of the fp32
-        # reference. "fp32": every contraction on the fp32 MFMA, fp32 activations, logits within 1e-4 - eval forward only
-        # (ssrs_amd/fp32_path.py). May be switched on a built model: model.precision = "fp32".
+        # reference. "fp32": every contraction on the fp32 MFMA, fp32 activations and gradients: logits within 1e-4, gradients
+        # pinned against the reference's at 1e-4 (tests/test_fp32_gpu.py); slow (no bf16 MFMA, unfused epilogues) - the mode for
+        # verification and for fp32 training runs. May be switched on a built model: model.precision = "fp32".
         self.precision = precision or os.environ.get("MFNET_PRECISION", "bf16")
         if self.precision not in ("bf16", "fp32"):
             raise ValueError(f"precision {self.precision!r}: 'bf16' or 'fp32'")
@@ -333,8 +334,16 @@ class UNetFormer(nn.Module):
             raise NotImplementedError("the HIP path takes tiles whose height and width are multiples of 32 (an even token grid for the "
                                       "2x2 max-pool level); got %dx%d" % (x.shape[-2], x.shape[-1]))
         if self.precision == "fp32":
-            from .fp32_path import forward_fp32
-            return forward_fp32(self, x, y)
+            if not self.training and not torch.is_grad_enabled():
+                from .fp32_path import forward_fp32          # the lean inference forward (no saved tensors)
+                return forward_fp32(self, x, y)
+            # fp32 training (the reference trains in fp32, trainer.py:146-159): the same modules and backward passes as below with
+            # every activation, gradient and contraction in fp32 (ops.FP32); each autograd node's backward runs in that mode too
+            with D.ops.precision("fp32"):
+                return self._forward_train(x, y)
+        return self._forward_train(x, y)
+
+    def _forward_train(self, x, y):
         h, w = x.shape[-2:]
         B = x.shape[0]
         deep = self.image_encoder.forward_stacked(x, y)             # [2B, H/16, W/16, 256] channels-last

@@ -49,12 +49,12 @@ def _cached(key, params, build):
 
 def w_bf16(p: torch.Tensor, tag="") -> torch.Tensor:
     """bf16 copy of a frozen [N,K] weight."""
-    return _cached(("w", tag), (p,), lambda: ops.cast(p.detach().reshape(p.shape[0], -1).contiguous(), BF))
+    return _cached(("w", tag, ops.FP32), (p,), lambda: ops.cast(p.detach().reshape(p.shape[0], -1).contiguous(), BF))
 
 
 def wT_bf16(p: torch.Tensor, tag="") -> torch.Tensor:
     """bf16 copy of the transpose [K,N] of a frozen [N,K] weight (operand of the dgrad GEMM)."""
-    return _cached(("wT", tag), (p,),
+    return _cached(("wT", tag, ops.FP32), (p,),
                    lambda: ops.cast(p.detach().reshape(p.shape[0], -1).t().contiguous(), BF))
 
 
@@ -101,7 +101,7 @@ def _stack2(kind, a, b, transpose=False):
 
 def _ln_lora_fits(R, C):
     """the fused LayerNorm + down-projection kernel keeps both modalities' A as bf16 in 64 KB of LDS"""
-    return 2 * R * C * 2 + 512 <= 65536
+    return 2 * R * C * 2 + 512 <= 65536 and not ops.FP32          # (a bf16 kernel: fp32 training takes the general products)
 
 
 def _down(x_bf, A_x, A_y, half):
@@ -142,14 +142,35 @@ def _tn_groups(y_bf, u, half, transposed, scale=1.0):
     return o[0], o[1]
 
 
+def _rel_tables32(attn: nn.Module, kh: int, kw: int):
+    """get_rel_pos's resized tables (lora_block.py:260-271) as fp32 [2k-1, hd] matrices; frozen, cached per window size."""
+    return _cached(("rel32", kh, kw), (attn.rel_h, attn.rel_w),
+                   lambda: (_resize_rel(attn.rel_h.detach().float(), 2 * kh - 1).contiguous(),
+                            _resize_rel(attn.rel_w.detach().float(), 2 * kw - 1).contiguous()))
+
+
 def _attention(qkv, attn_mod, G, Sh, Sw, heads, ws):
+    """-> (o, lse, tables). fp32 training (fp32 qkv): the fp32 attention kernel, whose backward recomputes the row statistics
+    (lse is None) and takes the two resized fp32 tables instead of the stacked bf16 one."""
     kh, kw = (ws, ws) if ws > 0 else (Sh, Sw)
-    tbl, tblT, Lh, Lw = _rel_tables(attn_mod, kh, kw)
     hd = qkv.shape[1] // (3 * heads)
+    if qkv.dtype == torch.float32:
+        th, tw = _rel_tables32(attn_mod, kh, kw)
+        return ops.attn_f32(qkv, attn_mod.qkv.bias.detach(), th, tw, G, Sh, Sw, heads, ws, hd ** -0.5), None, (th, tw, 0, 0)
+    tbl, tblT, Lh, Lw = _rel_tables(attn_mod, kh, kw)
     o, lse = ops.attn_fwd(qkv, attn_mod.qkv.bias, tbl, G, Sh, Sw, heads, ws, Lh, Lw, hd ** -0.5)
     return o, lse, (tbl, tblT, Lh, Lw)
 
 
+def _attention_bwd(qkv, attn_mod, tb, o, dO, lse, G, Sh, Sw, heads, ws):
+    tbl, tblT, Lh, Lw = tb
+    hd = qkv.shape[1] // (3 * heads)
+    if qkv.dtype == torch.float32:
+        return ops.attn_f32_bwd(qkv, attn_mod.qkv.bias.detach(), tbl, tblT, o, dO, G, Sh, Sw, heads, ws, hd ** -0.5)
+    return ops.attn_bwd(qkv, attn_mod.qkv.bias, tbl, tblT, o, dO, lse, G, Sh, Sw, heads, ws, Lh, Lw, hd ** -0.5)
+
+
+@ops.keeps_precision
 class _LoraAttnBranch(torch.autograd.Function):
     """h -> h + proj(attn(qkv_lora(LN1(h))))  for the stacked token matrix (lora_block.py:64-82)."""
 
@@ -172,7 +193,7 @@ class _LoraAttnBranch(torch.autograd.Function):
                        n_groups=2, lr_scale=1.0 / r)
         o, lse, tb = _attention(qkv, attn, 2 * B, Sh, Sw, heads, ws)
         out = ops.gemm(o, w_bf16(attn.proj.weight), bias=attn.proj.bias, residual=h2, out_dtype=torch.float32)
-        ctx.save_for_backward(h2, mean, rstd, ln, a, qkv, o, lse)
+        ctx.save_for_backward(h2, mean, rstd, ln, a, qkv, o, lse)          # (lse: None in fp32 mode)
         ctx.blk, ctx.geom, ctx.tb = blk, geom, tb
         ctx.params = (Ax, Ay, Bx, By)
         return out.view(h.shape)
@@ -180,7 +201,7 @@ class _LoraAttnBranch(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         h2, mean, rstd, ln, a, qkv, o, lse = ctx.saved_tensors
-        blk, (B, Sh, Sw, heads, ws), (tbl, tblT, Lh, Lw) = ctx.blk, ctx.geom, ctx.tb
+        blk, (B, Sh, Sw, heads, ws) = ctx.blk, ctx.geom
         Ax, Ay, Bx, By = ctx.params
         attn = blk.attn
         M, D = h2.shape
@@ -190,9 +211,9 @@ class _LoraAttnBranch(torch.autograd.Function):
         d2 = dout.reshape(M, D).contiguous()
         d_bf = ops.bf16_of(d2)
         dO = ops.gemm(d_bf, wT_bf16(attn.proj.weight))
-        dqkv = ops.attn_bwd(qkv, attn.qkv.bias, tbl, tblT, o, dO, lse, 2 * B, Sh, Sw, heads, ws, Lh, Lw, hd ** -0.5)
+        dqkv = _attention_bwd(qkv, attn, ctx.tb, o, dO, lse, 2 * B, Sh, Sw, heads, ws)
         s = 1.0 / r
-        if 2 * r == 8:
+        if 2 * r == 8 and not ops.FP32:
             # one pass over dqkv for d(xA^T) = dqkv . B (per modality) and dB = dqkv^T . a; one over ln for dA^T = ln^T . da
             dV, pp = ops.lora_side(dqkv, U=a, Vt=_qkv_lora_V(Bx, By, D, r, transposed=True), n_groups=2, scale=s)
             da = ops.reduce_parts(pp, s)
@@ -221,7 +242,7 @@ def _mix_linear_fwd(x_bf, lin, half, act, residual, aU=None):
     K = x_bf.shape[-1]
     if aU is not None:
         a, U = aU
-    elif r in (4, 8) and half % 2 == 0 and K % 8 == 0 and K <= 4096 and 2 * r * K * 2 + 512 <= 96 * 1024 and x_bf.shape[0] == 2 * half:
+    elif not ops.FP32 and r in (4, 8) and half % 2 == 0 and K % 8 == 0 and K <= 4096 and 2 * r * K * 2 + 512 <= 96 * 1024 and x_bf.shape[0] == 2 * half:
         a, U = ops.lora_down_mix(x_bf, _stack2("A", lin.lora_Ax, lin.lora_Ay), lin.lora_wx.detach(), lin.lora_wy.detach())
     else:
         a = _down(x_bf, lin.lora_Ax, lin.lora_Ay, half)
@@ -242,7 +263,7 @@ def _mix_linear_bwd(d_bf, x_bf, lin, saved, half, gelu_aux=None):
     input was GELU(pre) (then dx is the grad w.r.t. pre)."""
     a, U = saved
     r = a.shape[1]
-    if 2 * r == 8:
+    if 2 * r == 8 and not ops.FP32:
         dV, pp = ops.lora_side(d_bf, U=U, Vt=_mix_V(lin, transposed=True))      # d_bf is read once for P = d . [Bx|By] and dB
         da, dw = ops.lora_mix_bwd(pp, a, lin.lora_wx, lin.lora_wy)
         dA = ops.lora_side(x_bf, U=da, n_groups=2)[0]
@@ -257,6 +278,7 @@ def _mix_linear_bwd(d_bf, x_bf, lin, saved, half, gelu_aux=None):
     return dx, (dAx, dAy, dV[:, :r], dV[:, r:], dw[0:1], dw[1:2])
 
 
+@ops.keeps_precision
 class _LoraMlpBranch(torch.autograd.Function):
     """h -> h + lin2(gelu(lin1(LN2(h))))  with the cross-modal LoRA mix (lora_block.py:83-85,104-108)."""
 
@@ -295,6 +317,7 @@ class _LoraMlpBranch(torch.autograd.Function):
         return (dh.view(dout.shape), None) + deliver(blk._mlp_params(), g1 + g2)     # order of LoraBlock._mlp_params()
 
 
+@ops.keeps_precision
 class _Neck(torch.autograd.Function):
     """frozen neck: 1x1 conv -> LayerNorm2d -> 3x3 conv -> LayerNorm2d on channels-last tokens
     (image_encoder.py:104-120,142-143). h [G,Sh,Sw,D] fp32 -> [G,Sh,Sw,256] fp32."""
@@ -334,15 +357,15 @@ class _Neck(torch.autograd.Function):
 
 
 def _neck3x3_w(w):     # [O, I, 3, 3] -> [O, 9*I] with k = tap*I + c  (im2col3x3 order)
-    return _cached(("n3",), (w,), lambda: ops.cast(w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous(), BF))
+    return _cached(("n3", ops.FP32), (w,), lambda: ops.cast(w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous(), BF))
 
 
 def _neck3x3_wflipT(w):   # [O, I, 3, 3] -> [I, 9*O] with k = (8 - tap)*O + o: the data gradient as a 3x3 conv of dy
-    return _cached(("n3fT",), (w,), lambda: ops.cast(w.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], -1).contiguous(), BF))
+    return _cached(("n3fT", ops.FP32), (w,), lambda: ops.cast(w.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], -1).contiguous(), BF))
 
 
 def _neck3x3_wT(w):
-    return _cached(("n3T",), (w,), lambda: ops.cast(w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).t().contiguous(), BF))
+    return _cached(("n3T", ops.FP32), (w,), lambda: ops.cast(w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).t().contiguous(), BF))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -398,6 +421,7 @@ class Linear(nn.Linear, LoRALayer):
         return out[0], out[1]
 
 
+@ops.keeps_precision
 class _StandaloneMixLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, lin, *params):
@@ -512,6 +536,7 @@ class LayerNorm2d(nn.Module):
 # ---------------------------------------------------------------------------------------------
 # blocks
 # ---------------------------------------------------------------------------------------------
+@ops.keeps_precision
 class _Gelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from . import ops
 from .bank import deliver, derived, weight_bf16
-from .vit import BF, Adapter, _attention, _geom, w_bf16, wT_bf16
+from .vit import BF, Adapter, _attention, _attention_bwd, _geom, w_bf16, wT_bf16
 
 
 class Attention(nn.Module):
@@ -80,6 +80,7 @@ def _dense_bwd(d_bf, x_bf, Wx, Wy, half, gelu_aux=None):
     return dx, dW, db
 
 
+@ops.keeps_precision
 class _AdapterAttnBranch(torch.autograd.Function):
     """h -> h + A(o), o = proj(attn(qkv(LN1(h)))), A(o) = o + fc2(gelu(fc1(o))) with Img_Adapter weights
     on the RGB rows and DSM_Adapter weights on the DSM rows (adapter_fusionblock.py:78-100)."""
@@ -108,7 +109,7 @@ class _AdapterAttnBranch(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         (h2, mean, rstd, qkv, o, lse, op, a, p, w1x, w2x, w1y, w2y) = ctx.saved_tensors
-        blk, (B, Sh, Sw, heads, ws), (tbl, tblT, Lh, Lw) = ctx.blk, ctx.geom, ctx.tb
+        blk, (B, Sh, Sw, heads, ws) = ctx.blk, ctx.geom
         attn = blk.attn
         M, D = h2.shape
         half = M // 2
@@ -123,13 +124,14 @@ class _AdapterAttnBranch(torch.autograd.Function):
         if not ctx.needs_input_grad[0]:          # first block over a frozen patch embedding: the (frozen) attention needs no backward
             return (None, None, None) + deliver(ctx.params, grads)
         dO = ops.gemm(dop, wT_bf16(attn.proj.weight))
-        dqkv = ops.attn_bwd(qkv, attn.qkv.bias, tbl, tblT, o, dO, lse, 2 * B, Sh, Sw, heads, ws, Lh, Lw, hd ** -0.5)
+        dqkv = _attention_bwd(qkv, attn, ctx.tb, o, dO, lse, 2 * B, Sh, Sw, heads, ws)
         dln = ops.gemm(dqkv, wT_bf16(attn.qkv.weight))
         dh, dh_bf = ops.layernorm_bwd(dln, h2, mean, rstd, blk.norm1.weight, dres=d2, want_bf16=True)
         ops.remember_bf16_twin(dh, dh_bf)
         return (dh.view(dout.shape), None, None) + deliver(ctx.params, grads)
 
 
+@ops.keeps_precision
 class _AdapterMlpBranch(torch.autograd.Function):
     """h -> h + mlp(LN2(h)) + mix(MLPx_Adapter(xn), MLPy_Adapter(yn))  (adapter_fusionblock.py:101-108)."""
 

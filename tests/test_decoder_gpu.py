@@ -13,7 +13,11 @@ a float64 one, not of the backward kernels). The backward kernels are therefore 
   * generic detfill weights (switches active, masks exercised): within 1e-1 relative L2.
 Per-channel gradients (BatchNorm weight / bias: column sums over all pixels, where terms of both signs cancel)
 get twice the bound; the 2-element fusion weights (one fully cancelling sum each) are compared in the linear
-regime only."""
+regime only.
+
+precision = "fp32" (fp32 training, ops.precision("fp32")): the same module code with every contraction on the fp32 MFMA.
+In the linear regime nothing can flip, and outputs AND every gradient are held to 1e-4 - the fp32 pin of the decoder / FPN
+backward passes; with generic weights the few switches that fp32 rounding still flips bound the gradients at 3e-2."""
 import argparse
 import warnings
 
@@ -28,6 +32,19 @@ from ssrs_amd import detfill
 
 pytestmark = pytest.mark.gpu
 OUT_TOL, GRAD_L2, GRAD_MAX = 2e-2, 3e-2, 0.25
+PRECISIONS = ["bf16", "fp32"]
+
+
+def _tols(precision, linear):
+    """(output tolerance, gradient relative-L2 tolerance, gradient max-norm tolerance)"""
+    if precision == "fp32":
+        return 1e-4, (1e-4 if linear else 3e-2), (1e-3 if linear else 0.5)
+    return OUT_TOL, (GRAD_L2 if linear else 1e-1), (GRAD_MAX if linear else 1.0)
+
+
+def _mode(precision):
+    from ssrs_amd import ops
+    return ops.precision(precision)
 
 
 def _linear_regime(sd):
@@ -73,9 +90,8 @@ def _req(sd, prefix):
     return out, leaves
 
 
-def _check_grads(module, prefix, leaves, linear=True):
-    GRAD_L2 = 3e-2 if linear else 1e-1
-    GRAD_MAX = 0.25 if linear else 1.0
+def _check_grads(module, prefix, leaves, linear=True, precision="bf16"):
+    _, GRAD_L2, GRAD_MAX = _tols(precision, linear)
     bad = {}
     n = 0
     for name, p in module.named_parameters():
@@ -96,10 +112,11 @@ def _check_grads(module, prefix, leaves, linear=True):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("linear", [True, False])
 @pytest.mark.parametrize("training", [True, False])
 @pytest.mark.parametrize("name,B,S", [("b3", 2, 16), ("b4", 3, 8), ("b2", 1, 32), ("b3", 2, 12), ("b2", 1, 20)])
-def test_block(name, B, S, training, linear):
+def test_block(name, B, S, training, linear, precision):
     # S = 12 / 20: maps that are not multiples of the 8x8 window - GlobalLocalAttention.pad's reflect branch (:149-155)
     m, sd = _model(f"dec_block_{name}", linear=linear)
     blk = getattr(m.decoder, name).train(training)
@@ -107,28 +124,31 @@ def test_block(name, B, S, training, linear):
     x = _u(f"blk/{name}/x", (B, 64, S, S), 1.5)
     g = _u(f"blk/{name}/g", (B, 64, S, S))
     xg = x.cuda().requires_grad_()
-    out = blk(xg)
+    out_tol, l2_tol, _ = _tols(precision, linear)
+    with _mode(precision):
+        out = blk(xg)
     out.backward(g.cuda())
     sdr, leaves = _req(sd, prefix)
     xd = x.double().requires_grad_()
     st = R.BNState(training)
     ref = R.decoder_block(sdr, prefix, xd, st, 8, 8)
     ref.backward(g.double())
-    assert rel_err(out, ref) < OUT_TOL
-    assert rel_l2(xg.grad, xd.grad) < (GRAD_L2 if linear else 1e-1)
-    _check_grads(blk, prefix, leaves, linear)
+    assert rel_err(out, ref) < out_tol
+    assert rel_l2(xg.grad, xd.grad) < l2_tol, rel_l2(xg.grad, xd.grad)
+    _check_grads(blk, prefix, leaves, linear, precision)
     if training:      # running statistics updated like nn.BatchNorm2d
         for k, v in st.updates.items():
             if k.startswith(prefix):
                 got = m.state_dict()[k]
                 # 3e-3: statistics of bf16 activations over as few as 288 positions (S=12): measured 1.3e-3 there
-                assert rel_err(got, v) < (3e-3 if got.dtype.is_floating_point else 1e-12), k
+                assert rel_err(got, v) < ((3e-3 if precision == "bf16" else 1e-4) if got.dtype.is_floating_point else 1e-12), k
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("linear", [True, False])
 @pytest.mark.parametrize("training", [True, False])
 @pytest.mark.parametrize("name", ["p3", "p1"])
-def test_wf_and_frh(name, training, linear):
+def test_wf_and_frh(name, training, linear, precision):
     m, sd = _model(f"dec_fuse_{name}", linear=linear)
     mod = getattr(m.decoder, name).train(training)
     prefix = f"decoder.{name}."
@@ -137,17 +157,18 @@ def test_wf_and_frh(name, training, linear):
     res = _u(f"fuse/{name}/res", (B, 256, S, S), 1.5).to(torch.bfloat16).float()      # what the bf16 pyramid holds
     g = _u(f"fuse/{name}/g", (B, 64, S, S))
     xg, rg = x.cuda().requires_grad_(), res.cuda().requires_grad_()
-    out = mod(xg, rg)
+    out_tol, tol, _ = _tols(precision, linear)
+    with _mode(precision):
+        out = mod(xg, rg)
     out.backward(g.cuda())
     sdr, leaves = _req(sd, prefix)
     xd, rd = x.double().requires_grad_(), res.double().requires_grad_()
     st = R.BNState(training)
     ref = (R.wf if name == "p3" else R.feature_refinement_head)(sdr, prefix, xd, rd, st)
     ref.backward(g.double())
-    assert rel_err(out, ref) < OUT_TOL
-    tol = GRAD_L2 if linear else 1e-1
+    assert rel_err(out, ref) < out_tol
     assert rel_l2(xg.grad, xd.grad) < tol and rel_l2(rg.grad, rd.grad) < tol, (rel_l2(xg.grad, xd.grad), rel_l2(rg.grad, rd.grad))
-    _check_grads(mod, prefix, leaves, linear)
+    _check_grads(mod, prefix, leaves, linear, precision)
 
 
 def _unshuffle(t, B, h, w, perm):
@@ -173,20 +194,24 @@ def _shuffle(nchw, B, h, w, perm):
     return r.reshape(B, h, 2, 2, w, 2, 2, C).permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(-1, C)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("training", [True, False])
-def test_fpn_and_se_fusion(training):
+def test_fpn_and_se_fusion(training, precision):
     from ssrs_amd import decoder_ops as D
     m, sd = _model("dec_fpn")
     m.train(training)
     B, S = 2, 16
     deep = _u("fpn/deep", (2 * B, S, S, 256), 1.5)
     dg = deep.cuda().requires_grad_()
-    res = D.FpnFusionFn.apply(dg, m, training, *D.fpn_fusion_params(m))
+    out_tol, l2_tol, _ = _tols(precision, True)
+    with _mode(precision):
+        res = D.FpnFusionFn.apply(dg, m, training, *D.fpn_fusion_params(m))
+    gdt = torch.bfloat16 if precision == "bf16" else torch.float32          # the decoder hands the pyramid's gradients over in the activation type
     perms = (2, 1, 0, 0)
     sizes = (4 * S, 2 * S, S, S // 2)
     gs = [_u(f"fpn/g{i}", (B, 256, sizes[i], sizes[i])) for i in range(4)]
     base = (S, S, S, S // 2)
-    torch.autograd.backward(list(res), [_shuffle(gs[i].cuda(), B, base[i], base[i], perms[i]).to(torch.bfloat16).contiguous() for i in range(4)])
+    torch.autograd.backward(list(res), [_shuffle(gs[i].cuda().to(torch.bfloat16), B, base[i], base[i], perms[i]).to(gdt).contiguous() for i in range(4)])
     prefixes = tuple(f"fpn{i}{mm}." for i in (1, 2) for mm in "xy") + tuple(f"fusion{i}." for i in (1, 2, 3, 4))
     sdr, leaves = dict(sd), {}
     for k, v in sd.items():
@@ -201,8 +226,8 @@ def test_fpn_and_se_fusion(training):
     torch.autograd.backward(ref, [g.to(torch.bfloat16).double() for g in gs])
     for i in range(4):
         got = _unshuffle(res[i].float(), B, base[i], base[i], perms[i])
-        assert rel_err(got, ref[i]) < OUT_TOL, i
-    assert rel_l2(dg.grad, dd.grad) < GRAD_L2, rel_l2(dg.grad, dd.grad)
+        assert rel_err(got, ref[i]) < out_tol, i
+    assert rel_l2(dg.grad, dd.grad) < l2_tol, rel_l2(dg.grad, dd.grad)
     bad = {}
     for k, leaf in leaves.items():
         mod_name, _, pname = k.partition(".")
@@ -211,14 +236,15 @@ def test_fpn_and_se_fusion(training):
         if leaf.grad is None or leaf.grad.norm() < 1e-9:
             continue
         l2 = rel_l2(p.grad, leaf.grad)
-        if l2 > GRAD_L2:
-            bad[k] = round(l2, 4)
+        if l2 > l2_tol:
+            bad[k] = l2
     assert not bad, bad
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("linear", [True, False])
 @pytest.mark.parametrize("training,drop", [(False, False), (True, False), (True, True)])
-def test_decoder_end_to_end(training, drop, linear):
+def test_decoder_end_to_end(training, drop, linear, precision):
     """Decoder.forward (NCHW interface, raster-order pyramid) incl. segmentation head, Dropout2d with a fixed
     mask and the final x4 bilinear upsample, vs the oracle decoder."""
     m, sd = _model("dec_full", linear=linear)
@@ -235,7 +261,8 @@ def test_decoder_end_to_end(training, drop, linear):
         mask = (torch.bernoulli(torch.full((B, 64), 0.9, device="cuda")) / 0.9).cpu()
         torch.cuda.set_rng_state(state)               # the product draws the same mask
         assert (mask == 0).any()
-    out = dec(rg[0], rg[1], rg[2], rg[3], 16 * S, 16 * S)
+    with _mode(precision):
+        out = dec(rg[0], rg[1], rg[2], rg[3], 16 * S, 16 * S)
     out.backward(g.cuda())
     sdr, leaves = _req(sd, "decoder.")
     rd = [r.double().requires_grad_() for r in res]
@@ -245,8 +272,10 @@ def test_decoder_end_to_end(training, drop, linear):
                     drop_mask=None if mask is None else mask.double()[:, :, None, None])
     ref.backward(g.double())
     assert out.shape == ref.shape
-    assert rel_err(out, ref) < OUT_TOL
+    assert rel_err(out, ref) < _tols(precision, linear)[0]
     tol = 2 * GRAD_L2 if linear else 0.25          # deep chain of 3 blocks + 3 fusions: 2x the per-module bound
+    if precision == "fp32":
+        tol = 1e-4 if linear else 5e-2
     for i in range(4):
         assert rel_l2(rg[i].grad, rd[i].grad) < tol, (i, rel_l2(rg[i].grad, rd[i].grad))
     bad = {}
@@ -259,7 +288,7 @@ def test_decoder_end_to_end(training, drop, linear):
         if p.numel() <= 4 and not linear:
             continue
         if l2 > tol * (3 if p.numel() <= 4 else (2 if p.dim() == 1 else 1)):
-            bad[name] = round(l2, 4)
+            bad[name] = l2
     assert not bad, bad
 
 
