@@ -36,13 +36,13 @@ HBM_PEAK_GBS = 8000.0               # HBM3E spec (6.3 TB/s is what a float4 copy
 TRAIN_GF_PER_TILE = {"sam_lora": 191.0, "sam_adpt": 211.0}     # SURVEY.md 8(d), tools/flops.py
 
 
-def build_model(mod, encoder, num_classes, device):
+def build_model(mod, encoder, num_classes, device, precision="bf16"):
     from ssrs_amd import detfill
     from ssrs_amd.unetformer_mmsam import UNetFormer
     args = argparse.Namespace(mod=mod, mid_dim=None, image_size=1024, multimask_output=1)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        m = UNetFormer(num_classes=num_classes, encoder=encoder, args=args)
+        m = UNetFormer(num_classes=num_classes, encoder=encoder, args=args, precision=precision)
     # random-init weights of the right architecture from the closed-form fill (no checkpoint offline)
     m.load_state_dict(detfill.fill_state_dict(m.state_dict(), "bench/"))
     return m.to(device).train()
@@ -98,8 +98,12 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a HIP graph")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"], help="fp32: the fp32 training mode (every contraction on the fp32 MFMA; a side "
+                    "measurement - the headline metric is the bf16 step)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the with_h2d leg (steps fed from pinned host memory through the prefetcher)")
     a = ap.parse_args()
+    if a.precision == "fp32":
+        a.no_roofline = True             # the roofline legs trace the bf16 MFMA GEMM launches
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -164,7 +168,7 @@ def main():
 
     from ssrs_amd import detfill, ops
     from ssrs_amd.trainer import TrainEngine
-    model = build_model(a.mod, a.encoder, a.classes, dev)
+    model = build_model(a.mod, a.encoder, a.classes, dev, a.precision)
     eng = TrainEngine(model, lr=0.01, momentum=0.9, weight_decay=5e-4, class_weight=torch.ones(a.classes, device=dev),
                       use_graph=not a.eager, exchange_when_alone=rehearsal == "nccl1")
     rgb, dsm, tgt = detfill.tiles(f"bench/rank{rank}", a.batch, a.tile, a.classes)
@@ -343,13 +347,13 @@ def main():
 
     if rank == 0:
         tiles = world * a.batch * a.steps
-        base_cfg = a.mod == "sam_lora" and a.encoder == "vit_b" and a.tile == 256
+        base_cfg = a.mod == "sam_lora" and a.encoder == "vit_b" and a.tile == 256 and a.precision == "bf16"
         out = {"metric": "train tiles/sec (256x256 RGB+DSM, ViT-B MMLoRA)" if base_cfg else f"train tiles/sec ({a.tile}x{a.tile} RGB+DSM, {a.encoder} {a.mod})",
                "value": round(tiles / dt, 2), "unit": "tiles/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "bf16", "data": "synthetic",
+               "dtype": a.precision, "data": "synthetic",
                "config": {"workload": f"{a.encoder} {a.mod} fine-tune step (fwd+CE+bwd+SGD), {a.batch} tiles of {a.tile}x{a.tile} RGB+DSM per GPU, "
-                                      f"{a.classes} classes, bf16 MFMA / fp32 accumulate+master" + (" (BASELINE configs[1])" if base_cfg and a.batch == 16 else ""),
+                                      f"{a.classes} classes, " + ("bf16 MFMA / fp32 accumulate+master" if a.precision == "bf16" else "fp32 MFMA, fp32 activations and gradients") + (" (BASELINE configs[1])" if base_cfg and a.batch == 16 else ""),
                           "tiles_per_gpu": a.batch, "global_batch": world * a.batch, "parallelism": f"dp{world}"},
                "loss": round(metrics["loss"], 5),
                "algorithmic_train_tflops": (round(world * a.batch * TRAIN_GF_PER_TILE.get(a.mod, 191.0) * 1e9 / (dt / a.steps) / 1e12, 2)

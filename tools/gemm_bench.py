@@ -21,10 +21,13 @@ SHAPES = [(8192, 3072, 768, "lin1 fwd: bias+lora+gelu+pre"), (8192, 3072, 768, "
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--rotate", type=int, default=0, help="keep the last N results alive and cycle N copies of the activation operand: every "
+                    "launch reads and writes fresh addresses (N x footprint > the 256 MB MALL), like the GEMMs inside a train step")
+    ap.add_argument("--only", type=int, default=0, help="only the first N shapes")
     a = ap.parse_args()
     dev = torch.device("cuda")
     torch.manual_seed(0)
-    for M, N, K, kind in SHAPES:
+    for M, N, K, kind in (SHAPES[:a.only] if a.only else SHAPES):
         x = (torch.rand(M, K, device=dev) * 2 - 1).to(torch.bfloat16)
         w = (torch.rand(N, K, device=dev) * 2 - 1).to(torch.bfloat16)
         kw = {}
@@ -56,10 +59,23 @@ def main():
             err = float("nan")
         for _ in range(3):
             ops.gemm(x, w, **kw)
+        xs = [x.clone() for _ in range(a.rotate)] or [x]
+        kws = [dict(kw) for _ in xs]
+        for k2 in kws[1:]:
+            for name in ("aux", "residual"):
+                if name in k2:
+                    k2[name] = k2[name].clone()
+        ring = []
+        for i in range(2 * len(xs)):
+            ring.append(ops.gemm(xs[i % len(xs)], w, **kws[i % len(xs)]))
+            if len(ring) > a.rotate:
+                ring.pop(0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(a.reps):
-            ops.gemm(x, w, **kw)
+        for i in range(a.reps):
+            ring.append(ops.gemm(xs[i % len(xs)], w, **kws[i % len(xs)]))
+            if len(ring) > a.rotate:
+                ring.pop(0)
         e1.record()
         torch.cuda.synchronize()
         us = 1e3 * e0.elapsed_time(e1) / a.reps
