@@ -152,6 +152,8 @@ def _coords4(tuples, H, W, h, w, device):
     for r, c, vh, vw in tuples:
         if not (0 <= r and 0 <= c and 1 <= vh <= h and 1 <= vw <= w and r + vh <= H and c + vw <= W):
             raise ValueError(f"window (row {r}, col {c}, {vh}x{vw}) leaves the {H}x{W} raster or its {h}x{w} tile")
+    if not tuples:
+        return torch.zeros((0, 4), dtype=torch.int32, device=device)
     return torch.tensor(list(tuples), dtype=torch.int32, device=device)
 
 
@@ -293,12 +295,15 @@ class SlidingWindowPredictor:
         d = ops.scale_shift(dsm.contiguous(), mm, 0)
         band = torch.zeros((C, max(1, me["hi"] - me["lo"]), W), dtype=self.accumulate, device=img.device)
         mine = coords[me["first"]:me["last"]]
-        for chunk in grouper(self.batch_size, mine):
-            c4 = _coords4([(r, c, h, w) for r, c in chunk], H, W, h, w, img.device)
+        # ONE host -> device copy of the whole window list: a per-batch `torch.tensor(..., device=)` is a pageable copy that waits for
+        # everything enqueued before it, i.e. it serialised the host's work of batch i + 1 behind the GPU's work of batch i
+        c4_all = _coords4([(r, c, h, w) for r, c in mine], H, W, h, w, img.device)
+        c2_all = (c4_all[:, :2] - torch.tensor([me["lo"], 0], dtype=torch.int32, device=img.device)).contiguous()
+        for i0 in range(0, len(mine), self.batch_size):
+            c4, c2 = c4_all[i0:i0 + self.batch_size], c2_all[i0:i0 + self.batch_size]
             rgb_t, dsm_t = ops.extract_tiles(img, d, c4, h, w)
             with self._ebank:
                 logits = self.forward(rgb_t, dsm_t).float().contiguous()
-            c2 = (c4[:, :2] - torch.tensor([me["lo"], 0], dtype=torch.int32, device=img.device)).contiguous()
             ops.tile_accumulate(band, logits, c2, atomic=True)              # pred[x:x+w, y:y+h] += out (evaluator.py:169-171)
         if world > 1 and rank < len(plan):
             merge_bands(band, plan, rank, _device_add_rows, self.group)
@@ -389,8 +394,10 @@ class RasterInference:
         rank, world = _dist_info(self.group)
         wins = get_sliding_windows(H, W, self.window_size, self.overlap)
         per = (len(wins) + world - 1) // world
-        for chunk in grouper(self.batch_size, wins[rank * per:(rank + 1) * per]):
-            c4 = _coords4([(y, x, ye - y, xe - x) for y, x, ye, xe in chunk], H, W, h, w, img.device)
+        mine = wins[rank * per:(rank + 1) * per]
+        c4_all = _coords4([(y, x, ye - y, xe - x) for y, x, ye, xe in mine], H, W, h, w, img.device)
+        for i0 in range(0, len(mine), self.batch_size):
+            chunk, c4 = mine[i0:i0 + self.batch_size], c4_all[i0:i0 + self.batch_size]
             rgb_t, dem_t = ops.extract_tiles(img, demc, c4, h, w)
             ops.tile_minmax_norm(dem_t)
             with self._ebank:
@@ -419,15 +426,17 @@ class RasterInference:
         # of the windows, the atomics and the ranks (ops.tile_prob_accumulate)
         band = torch.zeros((2, max(1, me["hi"] - me["lo"]), W), dtype=torch.int64, device=img.device)
         demc = dem.float().contiguous()
-        for chunk in grouper(self.batch_size, wins[me["first"]:me["last"]]):
-            c4 = _coords4([(y, x, ye - y, xe - x) for y, x, ye, xe in chunk], H, W, h, w, img.device)
+        mine = wins[me["first"]:me["last"]]
+        c4_all = _coords4([(y, x, ye - y, xe - x) for y, x, ye, xe in mine], H, W, h, w, img.device)      # one copy for the whole list
+        c4b_all = c4_all.clone()
+        c4b_all[:, 0] -= me["lo"]
+        for i0 in range(0, len(mine), self.batch_size):
+            c4, c4b = c4_all[i0:i0 + self.batch_size], c4b_all[i0:i0 + self.batch_size]
             rgb_t, dem_t = ops.extract_tiles(img, demc, c4, h, w)              # reflect-pads short tiles
             ops.tile_minmax_norm(dem_t)                                        # per-tile DSM min-max
             with self._ebank:
                 logits = self.forward(rgb_t, dem_t).float().contiguous()
-            c4b = c4.clone()
-            c4b[:, 0] -= me["lo"]
-            ops.tile_prob_accumulate(band[0], band[1], logits, c4b.contiguous(), self.cls)
+            ops.tile_prob_accumulate(band[0], band[1], logits, c4b, self.cls)
         if world > 1 and rank < len(plan):
             merge_bands(band, plan, rank, _int_add_rows, self.group)
         prob = torch.zeros((H, W), dtype=torch.float32, device=img.device)
