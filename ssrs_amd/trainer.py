@@ -455,18 +455,21 @@ class Trainer:
         nb = 0
         multi = dist.is_initialized() and dist.get_world_size() > 1
         for batch_idx, (data, dsm, target) in enumerate(self.train_loader):
+            if self.skip_empty:
+                # train_multiscale_main.py:113-125. Under data parallelism the decision is COLLECTIVE: a step is skipped
+                # only when every rank's batch is empty, so all ranks issue the same gradient collectives. Labels still in host
+                # memory (a plain DataLoader) are inspected there: on the device the answer costs a host sync per step.
+                valid = target[target != 255]
+                flag = 1 if (valid.numel() == 0 or bool(torch.all(valid == 0))) else 0
+                if multi:
+                    empty = torch.tensor([flag], device=dev, dtype=torch.int32)
+                    dist.all_reduce(empty, op=dist.ReduceOp.MIN)
+                    flag = int(empty.item())
+                if flag:
+                    continue
             data = data.to(dev, non_blocking=True)
             dsm = dsm.to(dev, non_blocking=True)
             target = target.to(dev, non_blocking=True)
-            if self.skip_empty:
-                # train_multiscale_main.py:113-125. Under data parallelism the decision is COLLECTIVE: a step is skipped
-                # only when every rank's batch is empty, so all ranks issue the same gradient collectives.
-                valid = target[target != 255]
-                empty = torch.tensor([1 if (valid.numel() == 0 or bool(torch.all(valid == 0))) else 0], device=dev, dtype=torch.int32)
-                if multi:
-                    dist.all_reduce(empty, op=dist.ReduceOp.MIN)
-                if int(empty.item()):
-                    continue
             acc = self.engine.step(data, dsm, target)
             pend += acc
             epoch_acc += acc
