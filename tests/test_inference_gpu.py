@@ -496,3 +496,48 @@ def test_device_jitter_vs_reference_golden():
     print(f"\n[device jitter] {off} of {tot} pixels one grey level away from the reference")
     assert off < 1e-3 * tot
     assert (ju8[:n] != r[:n]).sum() > 1000
+
+
+def test_full_size_raster_8192_properties():
+    """BASELINE configs[3] at its full size (an 8192 x 8192 raster, ViT-B MMLoRA) through both predictors, held to properties that do
+    not need a reference run of that size: on a non-overlapping grid every window's mask is the arg-max of a direct forward of
+    that window (one contribution per pixel; >= 99.5 % of the pixels - the rest are near-ties of a differently tiled GEMM); the blended probability raster of the inference.py grid is
+    bit-identical between two runs (int64 fixed-point blend) and within 2e-2 between batch sizes; its mask is the threshold of its
+    probability."""
+    from ssrs_amd.inference import RasterInference, SlidingWindowPredictor
+    from ssrs_amd.unetformer_mmsam import UNetFormer
+    args = argparse.Namespace(mod="sam_lora", mid_dim=None, image_size=1024, multimask_output=1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = UNetFormer(num_classes=2, encoder="vit_b", args=args)
+    m.load_state_dict(detfill.fill_state_dict(m.state_dict(), "raster8192/"))
+    m = m.cuda().eval()
+    S = 8192
+    g = torch.Generator(device="cuda").manual_seed(5)
+    img = torch.rand((3, S, S), device="cuda", generator=g)
+    dsm = 30.0 + 20.0 * torch.rand((S, S), device="cuda", generator=g)
+    fwd = lambda a, b: m(a, b)      # noqa: E731
+    p = SlidingWindowPredictor(fwd, 2, (256, 256), batch_size=32, graph=True)
+    mask = p.predict(img, dsm, 256)                                  # 1024 windows, no overlap
+    assert mask.shape == (S, S) and mask.dtype == torch.uint8
+    mm = dsm.min(), dsm.max()
+    d = (dsm - mm[0]) / (mm[1] - mm[0])
+    with torch.no_grad():
+        for (r, c) in ((0, 0), (7936, 7936), (256, 4096), (5120, 1280), (7936, 0)):
+            direct = m(img[None, :, r:r + 256, c:c + 256].contiguous(), d[None, r:r + 256, c:c + 256].contiguous()).argmax(1)[0]
+            # (a one-window forward takes other GEMM tile shapes than the 32-window batches: bf16-level differences may flip near-ties)
+            agree = float((direct.to(torch.uint8) == mask[r:r + 256, c:c + 256]).float().mean())
+            assert agree >= 0.995, (r, c, agree)
+    rgb8 = (img * 255).to(torch.uint8)
+    ri = RasterInference(fwd, (256, 256), overlap_ratio=0.25, batch_size=32, graph=True)
+    prob1, mask1 = ri.predict(rgb8, dsm)
+    prob2, mask2 = ri.predict(rgb8, dsm)
+    assert torch.equal(prob1, prob2) and torch.equal(mask1, mask2)
+    ri16 = RasterInference(fwd, (256, 256), overlap_ratio=0.25, batch_size=16)
+    prob3, mask3 = ri16.predict(rgb8[:, :2048, :2048].contiguous(), dsm[:2048, :2048].contiguous())
+    ri32 = RasterInference(fwd, (256, 256), overlap_ratio=0.25, batch_size=32)
+    prob4, mask4 = ri32.predict(rgb8[:, :2048, :2048].contiguous(), dsm[:2048, :2048].contiguous())
+    # other batch sizes take other GEMM tile shapes: the probabilities agree to the bf16 bound, the masks away from the threshold
+    assert float((prob3 - prob4).abs().max()) < 2e-2 and float((mask3 == mask4).float().mean()) > 0.99
+    assert torch.equal(mask1, (prob1 >= 0.5).to(torch.uint8))
+    assert 0.0 <= float(prob1.min()) and float(prob1.max()) <= 1.0
