@@ -316,7 +316,7 @@ def test_tiny_encoder_fp32_vs_reference(mod):
     assert not bad, bad
 
 
-def _train_step_fp32(tag, mod, encoder, ncls=6, with_oracle32=False):
+def _train_step_fp32(tag, mod, encoder, ncls=6, with_oracle32=False, ignore=None):
     """Two SGD steps of the fp32 path against the reference's recorded float64 step: train-mode logits, loss0 / loss1, updated
     parameters and BatchNorm buffers at the fp32 bar - and EVERY gradient (norm + leading slice).
 
@@ -336,7 +336,11 @@ def _train_step_fp32(tag, mod, encoder, ncls=6, with_oracle32=False):
     m.load_state_dict(detfill.fill_state_dict(m.state_dict(), tag + "/"))
     m = m.cuda().train()
     m.decoder.segmentation_head[1].p = 0.0
-    rgb, dsm, tgt = [t.cuda() for t in detfill.tiles(tag, 2, 256, ncls)]
+    rgb, dsm, tgt = detfill.tiles(tag, 2, 256, ncls)
+    if ignore is not None:
+        tgt = tgt.clone()
+        tgt[:, :32, :48] = ignore            # tools/make_goldens.py _train_step_arrays
+    rgb, dsm, tgt = rgb.cuda(), dsm.cuda(), tgt.cuda()
     opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.01, momentum=0.9, weight_decay=5e-4)
     losses, w = [], {}
     names = [str(n) for n in g["grad_names"]]
@@ -345,7 +349,7 @@ def _train_step_fp32(tag, mod, encoder, ncls=6, with_oracle32=False):
     for step in range(2):
         opt.zero_grad()
         out = m(rgb, dsm)
-        loss = F.cross_entropy(out.permute(0, 2, 3, 1).reshape(-1, ncls), tgt.view(-1))
+        loss = F.cross_entropy(out.permute(0, 2, 3, 1).reshape(-1, ncls), tgt.view(-1), **({} if ignore is None else {"ignore_index": ignore}))
         loss.backward()
         losses.append(loss.item())
         if step == 0:
@@ -392,6 +396,11 @@ def _train_step_fp32(tag, mod, encoder, ncls=6, with_oracle32=False):
 @pytest.mark.parametrize("mod", ["sam_lora", "sam_adpt"])
 def test_tiny_model_fp32_train_step_vs_reference(mod):
     _train_step_fp32(f"model_tiny_{mod}", mod, "vit_tiny_test", with_oracle32=True)
+
+
+def test_tiny_model_fp32_train_step_ignore_index_255():
+    """the reference's recorded 2-class step with `ignore_index=255` labels (train_multiscale_main.py:30-43)"""
+    _train_step_fp32("model_tiny_ignore255", "sam_lora", "vit_tiny_test", ncls=2, ignore=255)
 
 
 def test_vitb_fp32_train_step_vs_reference():
