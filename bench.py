@@ -290,10 +290,13 @@ def main():
         # process): the newest profiles/*_pmc.json of each kernel, produced by tools/pmc_traffic.py from two rocprofv3 runs
         import glob
 
+        traffic_files = []
+
         def stored_traffic(pattern):
             pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
             if pmc and a.mod == "sam_lora" and a.batch == 16 and a.encoder == "vit_b" and a.tile == 256:
                 with open(pmc[-1]) as f:
+                    traffic_files.append("profiles/" + os.path.basename(pmc[-1]))
                     return round(json.load(f)["traffic_bytes_per_launch"])
             return None
         tr_big = [t for t in tr if takes_big(t[3])]
@@ -361,6 +364,8 @@ def main():
         if roofline is not None:
             out["roofline"] = roofline
             out["roofline_all_gemm"] = roofline_all
+            # `traffic` cannot be read from inside the process: it is the PMC measurement of this build's last profiled run
+            out["traffic_source"] = {"files": traffic_files, "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/measure_round.sh), per launch"}
         if roofline_hbm is not None:
             out["roofline_hbm"] = roofline_hbm
         if not a.no_roofline:

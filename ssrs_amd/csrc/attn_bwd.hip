@@ -169,10 +169,13 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : ((NSG == 1 || ROWT) ? 3 : 2)) vo
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int kl = it * RPI + tid / CHS;
-      u32x4_t k4 = kkind[it] == 0 ? kv[it] : pad.k, v4 = kkind[it] == 0 ? vv[it] : pad.v;
-      if (kkind[it] == 2) { k4 = (u32x4_t){0u, 0u, 0u, 0u}; v4 = k4; }
-      *reinterpret_cast<u32x4_t*>(K_lds + kl * ROWB + ((ch ^ kswz(kl)) << 4)) = k4;
-      *reinterpret_cast<u32x4_t*>(V_lds + kl * ROWB + ((ch ^ kswz(kl)) << 4)) = v4;
+      // three exclusive stores under the execution mask instead of 16 selects per row: a window without padded keys (most of the
+      // work) takes the first branch as a whole
+      u32x4_t* kd = reinterpret_cast<u32x4_t*>(K_lds + kl * ROWB + ((ch ^ kswz(kl)) << 4));
+      u32x4_t* vd = reinterpret_cast<u32x4_t*>(V_lds + kl * ROWB + ((ch ^ kswz(kl)) << 4));
+      if (kkind[it] == 0) { *kd = kv[it]; *vd = vv[it]; }
+      else if (kkind[it] == 1) { *kd = pad.k; *vd = pad.v; }
+      else { *kd = (u32x4_t){0u, 0u, 0u, 0u}; *vd = (u32x4_t){0u, 0u, 0u, 0u}; }
     }
     if (!ROWT) att_stage_indicator(g, G_lds, kc, Nk, nsg, tid);
     __syncthreads();
@@ -202,15 +205,21 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : ((NSG == 1 || ROWT) ? 3 : 2)) vo
             }
           }
         }
-        const bool tail = kt * 64 + 64 > kvalid;       // only the window's last tile holds keys beyond Nk
+        if (kt * 64 + 64 > kvalid) {                   // only the window's last tile holds keys beyond Nk: a wave-uniform branch, so
+#pragma unroll                                         // the other tiles carry no compare / select per score (48 of 154 VALU per tile)
+          for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int r = 0; r < 4; ++r) {
+              float pr = __builtin_amdgcn_exp2f(fmaf(s[t][r], cs, -lse2));
+              if (kt * 64 + 16 * t + 4 * fq + r >= kvalid) pr = 0.f;
+              s[t][r] = pr * (dp[t][r] - delta);        // dS (unscaled)
+            }
+        } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float pr = __builtin_amdgcn_exp2f(fmaf(s[t][r], cs, -lse2));
-            if (tail && kt * 64 + 16 * t + 4 * fq + r >= kvalid) pr = 0.f;
-            s[t][r] = pr * (dp[t][r] - delta);          // dS (unscaled)
-          }
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[t][r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], cs, -lse2)) * (dp[t][r] - delta);
+        }
         if (ROWT) {
           float hs = 0.f;
 #pragma unroll

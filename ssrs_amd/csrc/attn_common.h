@@ -229,20 +229,19 @@ __device__ __forceinline__ void att_slot_fragments(const AttnGeom& g, const floa
 // Indicator rows of the chunk's keys: G[key][slot] = 1 for slot == KH-1-kh and slot == KH+KW-1-kw (bf16), zero
 // rows beyond Nk. Thread t fills half of key (t >> 1)'s row; images are [group][key][32 slots], 16-B chunks
 // XOR-swizzled by gswz(key).
+// one bf16 1.0 at slot d of a 4-slot half chunk (d outside [0, 4): nothing) - a 64-bit shift instead of a compare per slot
+__device__ __forceinline__ unsigned long long att_one_at(int d) {
+  return (unsigned)d < 4u ? (0x3f80ull << (16 * d)) : 0ull;
+}
 __device__ __forceinline__ void att_stage_indicator(const AttnGeom& g, unsigned char* G_lds, int kc, int Nk, int nsg, int tid) {
   const int key = tid >> 1, kg = kc + key;
-  int jh = -1, jw = -1;
+  int jh = -1 << 20, jw = -1 << 20;
   if (kg < Nk) { const int kh = att_div(kg, g.KW), kw = kg - kh * g.KW; jh = g.KH - 1 - kh; jw = g.KH + g.KW - 1 - kw; }
   for (int cidx = (tid & 1) * 2 * nsg; cidx < ((tid & 1) + 1) * 2 * nsg; ++cidx) {
     const int c = cidx >> 2, c4 = cidx & 3, s0 = 32 * c + 8 * c4;
+    const unsigned long long lo = att_one_at(jh - s0) | att_one_at(jw - s0), hi = att_one_at(jh - s0 - 4) | att_one_at(jw - s0 - 4);
     u32x4_t w;
-    unsigned int ww[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int a = s0 + 2 * i, b = a + 1;
-      ww[i] = ((a == jh || a == jw) ? 0x3f80u : 0u) | ((b == jh || b == jw) ? 0x3f800000u : 0u);
-    }
-    w.x = ww[0]; w.y = ww[1]; w.z = ww[2]; w.w = ww[3];
+    w.x = (unsigned)lo; w.y = (unsigned)(lo >> 32); w.z = (unsigned)hi; w.w = (unsigned)(hi >> 32);
     *reinterpret_cast<u32x4_t*>(G_lds + c * (ATT_KC * ATT_GROW) + key * ATT_GROW + ((c4 ^ gswz(key)) << 4)) = w;
   }
 }
