@@ -541,3 +541,29 @@ def test_full_size_raster_8192_properties():
     assert float((prob3 - prob4).abs().max()) < 2e-2 and float((mask3 == mask4).float().mean()) > 0.99
     assert torch.equal(mask1, (prob1 >= 0.5).to(torch.uint8))
     assert 0.0 <= float(prob1.min()) and float(prob1.max()) <= 1.0
+
+
+def test_prefetcher_delivers_every_batch_intact_and_in_order():
+    """ssrs_amd.data.Prefetcher (pinned double-buffered host -> device feeder of the train loop, train_multiscale_main.py:507-522):
+    nine distinct batches through two pinned slots, a busy consumer stream in between (the copy of batch i + 2 must not overwrite
+    the pinned buffer batch i is still being copied from), ragged last batch, and the DeviceAugment transform applied on the way."""
+    from ssrs_amd.data import DeviceAugment, Prefetcher
+    g = torch.Generator().manual_seed(11)
+    batches = []
+    for i in range(9):
+        n = 4 if i < 8 else 2
+        batches.append((torch.randint(0, 256, (n, 3, 64, 64), dtype=torch.uint8, generator=g),
+                        100 + 20 * torch.rand((n, 64, 64), generator=g), torch.randint(0, 6, (n, 64, 64), generator=g)))
+    busy = torch.rand(4096, 4096, device="cuda")
+    seen = 0
+    for i, (rgb, dsm, tgt) in enumerate(Prefetcher(iter(batches), "cuda")):
+        busy = busy @ busy * 1e-4                                    # keeps the consumer stream behind the copies
+        assert rgb.is_cuda and rgb.dtype == torch.uint8 and tgt.dtype == torch.int64
+        assert torch.equal(rgb.cpu(), batches[i][0]) and torch.equal(dsm.cpu(), batches[i][1]) and torch.equal(tgt.cpu(), batches[i][2]), i
+        seen += 1
+    assert seen == 9
+    aug = DeviceAugment(augment=False)
+    outs = list(Prefetcher(iter(batches[:3]), "cuda", transform=aug))
+    for i, (rgb, dsm, tgt) in enumerate(outs):
+        want = aug(batches[i][0].cuda(), batches[i][1].cuda(), batches[i][2].cuda())
+        assert rgb.dtype == torch.float32 and torch.equal(rgb, want[0]) and torch.equal(dsm, want[1]) and torch.equal(tgt, want[2])
